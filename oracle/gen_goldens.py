@@ -1,0 +1,272 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors from the REAL reference (build container only).
+
+Usage (from the repo root; /root/reference must exist):
+
+    python oracle/gen_goldens.py
+
+Imports nmndeep/Robust-Segmentation from /root/reference through the small stand-in packages in
+oracle/shims (timm / autoattack / torchvision are not installed here and do not influence the
+attack arithmetic), runs the reference functions on seeded inputs and writes the inputs plus the
+reference's outputs to tests/golden/*.npz.  Only data is written - never reference source.
+The GPU box has no /root/reference: tests there read the committed .npz files.
+"""
+import os
+import random
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("SEA_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True
+sys.path[:0] = [os.path.join(HERE, "shims"), REF, ROOT]
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def npz(name, **arrs):
+    conv = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = np.asarray(v)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **conv)
+    print("wrote", name, {k: (v.shape, str(v.dtype)) for k, v in conv.items()})
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    os.chdir(REF)
+    torch.set_num_threads(4)
+    torch.Tensor.cuda = lambda self, *a, **k: self  # semseg/val.py hard-codes .cuda()
+
+    import semseg.attacker as A
+    import semseg.val as V
+    from autoattack.other_utils import Logger
+    from semseg.metrics import Metrics
+    from semseg.utils.utils import ADE_WTS, VOC_WTS
+
+    from oracle.tiny_models import PointwiseNet, TinyConvNet, make_labels
+
+    # ---------------------------------------------------------------- constants
+    npz("g0_weights", voc=np.array(VOC_WTS, dtype=np.float64), ade=np.array(ADE_WTS, dtype=np.float64))
+
+    # ---------------------------------------------------------------- G1 losses + gradients
+    for C in (5, 21, 151):
+        g = torch.Generator().manual_seed(100 + C)
+        logits = torch.randn(2, C, 16, 16, generator=g) * 3
+        y = torch.randint(0, C, (2, 16, 16), generator=g)
+        # make ~60% of the pixels correctly classified so the mask is non-trivial
+        boost = torch.rand(2, 16, 16, generator=g) < 0.6
+        logits.scatter_add_(1, y.unsqueeze(1), (boost.float() * 6).unsqueeze(1))
+        y[torch.rand(2, 16, 16, generator=g) < 0.05] = -1
+        if C == 21:
+            w = torch.tensor(VOC_WTS)
+        elif C == 151:
+            w = torch.tensor(ADE_WTS)
+        else:
+            w = torch.rand(C, generator=g)
+        mask_bg = 1 - (y == -1).float()
+        out = dict(logits=logits, y=y, w=w)
+        for name in ("mask-ce-avg", "mask-ce-bal", "js-avg"):
+            z = logits.clone().requires_grad_(True)
+            lp = A.criterion_dict[name](z, y, w)
+            li = A.pixel_to_img_loss(lp, mask_bg)
+            (gr,) = torch.autograd.grad(li.sum(), [z])
+            key = name.replace("-", "_")
+            out[key + "_px"] = lp.detach()
+            out[key + "_img"] = li.detach()
+            out[key + "_grad"] = gr
+        z = logits.clone().requires_grad_(True)
+        lp = A.criterion_dict["ce-avg"](z, y)
+        li = A.pixel_to_img_loss(lp, mask_bg)
+        (gr,) = torch.autograd.grad(li.sum(), [z])
+        out.update(ce_px=lp.detach(), ce_img=li.detach(), ce_grad=gr)
+        pred = logits.max(1)[1]
+        ok = pred == y
+        out["pred"] = pred
+        out["acc_step0"] = ok.float().view(2, -1).mean(-1)            # attacker.py:370-371
+        ok2 = ok.clone()
+        ok2[y == -1] = True
+        out["acc_loop"] = ok2.float().view(2, -1).mean(-1)            # attacker.py:485-490
+        npz(f"g1_losses_C{C}", **out)
+
+    # argmax tie-break vector (first max wins)
+    t = torch.tensor([[1.0, 3.0, 3.0, 2.0], [5.0, 5.0, 5.0, 5.0], [-1.0, -2.0, -1.0, -3.0]])
+    npz("g1_argmax_ties", z=t, arg=t.max(1)[1])
+
+    # ---------------------------------------------------------------- G2 Linf step (lines 389-410 verbatim semantics)
+    g = torch.Generator().manual_seed(7)
+    cases = {}
+    for ci, (eps255, a) in enumerate([(4, 1.0), (8, 0.75), (6, 0.75), (12, 0.75), (16, 1.0)]):
+        eps = eps255 / 255.0
+        x = torch.rand(3, 3, 8, 12, generator=g)
+        x_old = (x + eps * (2 * torch.rand(x.shape, generator=g) - 1)).clamp(0, 1)
+        x_adv = (x + eps * (2 * torch.rand(x.shape, generator=g) - 1)).clamp(0, 1)
+        grad = torch.randn(x.shape, generator=g)
+        grad[torch.rand(x.shape, generator=g) < 0.1] = 0.0
+        step = (2.0 * eps * torch.ones(3, 1, 1, 1)) / torch.tensor([1.0, 2.0, 4.0]).view(3, 1, 1, 1)
+        grad2 = x_adv - x_old
+        z = x_adv + step * torch.sign(grad)
+        z = torch.clamp(torch.min(torch.max(z, x - eps), x + eps), 0.0, 1.0)
+        z = torch.clamp(torch.min(torch.max(x_adv + (z - x_adv) * a + grad2 * (1 - a), x - eps), x + eps), 0.0, 1.0)
+        # K5 pieces
+        u = torch.rand(x.shape, generator=g)
+        rs = (x.clone() + eps * (2 * u - 1)).clamp(0.0, 1.0)            # attacker.py:293-294
+        zz = x + (x_adv - x) * 1.7
+        proj = (x + (zz - x).clamp(-eps, eps)).clamp(0.0, 1.0)         # attacker.py:683-690
+        # K6 (val.py:209-214)
+        alpha = 1e-2
+        delta = (torch.rand(x.shape, generator=g) * 2 - 1) * eps
+        d = delta + alpha * torch.sign(grad)
+        d = (x + d).clamp(0.0, 1.0) - x
+        d = d.clamp(-eps, eps)
+        cases.update({f"c{ci}_" + k: v for k, v in dict(
+            eps=np.float64(eps), a=np.float64(a), x=x, x_old=x_old, x_adv=x_adv, grad=grad, step=step.view(3),
+            out=z, u=u, rs=rs, zz=zz, proj=proj, alpha=np.float64(alpha), delta=delta, delta_out=d).items()})
+    npz("g2_linf", **cases)
+
+    # ---------------------------------------------------------------- G3 counts / metrics
+    g = torch.Generator().manual_seed(11)
+    for C in (5, 21):
+        pred = torch.randint(0, C, (4, 24, 20), generator=g)
+        y = torch.randint(0, C, (4, 24, 20), generator=g)
+        y[pred == 3] = torch.where(torch.rand(int((pred == 3).sum()), generator=g) < 0.7, 3, 1)
+        y[y == C - 1] = 0            # class C-1 absent from the targets
+        pred[pred == C - 2] = 0      # class C-2 never predicted
+        y[torch.rand(y.shape, generator=g) < 0.07] = -1
+        p2 = pred.clone()
+        m_acc, a_acc, m_iou = A.compute_iou_acc(p2, y, C)
+        met = Metrics(C, -1, "cpu")
+        onehot_logits = torch.nn.functional.one_hot(pred, C).permute(0, 3, 1, 2).float()
+        met.update(onehot_logits, y)
+        ious, miou = met.compute_iou()
+        acc, macc, aacc = met.compute_pixel_acc()
+        f1, mf1 = met.compute_f1()
+        npz(f"g3_counts_C{C}", pred=pred, y=y, pred_after=p2, m_acc=m_acc, a_acc=a_acc, m_iou=m_iou,
+            hist=met.hist, ious=np.array(ious), miou=np.float64(miou), acc=np.array(acc),
+            macc=np.float64(macc), aacc=np.float64(aacc), f1=np.array(f1), mf1=np.float64(mf1))
+
+    # ---------------------------------------------------------------- G4 apgd_train trajectories
+    logger = Logger(None)
+    import io
+    import contextlib
+    for netname, Net in (("conv", TinyConvNet), ("pw", PointwiseNet)):
+        for C in (5, 21):
+            net = Net(C, seed=C)
+            g = torch.Generator().manual_seed(1000 + C)
+            x = torch.rand(3, 3, 16, 16, generator=g)
+            y = make_labels(net, x, ignore_frac=0.05, flip_frac=0.1, seed=C)
+            w = torch.tensor(VOC_WTS) if C == 21 else torch.rand(C, generator=g)
+            eps = 8.0 / 255
+            x_init = (x + eps * (2 * torch.rand(x.shape, generator=g) - 1)).clamp(0, 1)
+            for loss in ("mask-ce-avg", "mask-ce-bal", "js-avg"):
+                for n_iter in (10, 25):
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        xb, acc, lb, xba = A.apgd_train(
+                            net, x, y, "Linf", eps, n_iter=n_iter, use_rs=False, loss=loss,
+                            track_loss="ce-avg", logger=logger, x_init=x_init, num_classes=C, weights=w,
+                            early_stop=True)
+                    npz(f"g4_apgd_{netname}_C{C}_{loss}_{n_iter}", x=x, y=y, w=w, x_init=x_init,
+                        eps=np.float64(eps), x_best=xb, acc=acc, loss_best=lb, x_best_adv=xba)
+
+    # early-stop cases: the whole batch reaches zero pixel accuracy before n_iter (attacker.py:568-569)
+    for tag, (Net, kw, eps, loss, n_iter) in {
+        "a": (TinyConvNet, dict(seed=4, gain=3.0), 0.3, "js-avg", 30),
+        "b": (TinyConvNet, dict(seed=5, gain=3.0), 0.3, "mask-ce-avg", 30),
+        "c": (PointwiseNet, dict(seed=3, gain=8.0, bias=0.0), 0.25, "mask-ce-avg", 20),
+    }.items():
+        net = Net(5, **kw)
+        g = torch.Generator().manual_seed(77)
+        x = torch.rand(2, 3, 8, 8, generator=g)
+        y = make_labels(net, x, ignore_frac=0.0, flip_frac=0.0, seed=1)
+        calls = [0]
+        fwd = net.forward
+
+        def counted(inp, _f=fwd, _c=calls):
+            _c[0] += 1
+            return _f(inp)
+
+        net.forward = counted
+        with contextlib.redirect_stdout(io.StringIO()):
+            xb, acc, lb, xba = A.apgd_train(net, x, y, "Linf", eps, n_iter=n_iter, use_rs=False, loss=loss,
+                                            track_loss="ce-avg", logger=logger, num_classes=5, weights=None,
+                                            early_stop=True)
+        npz(f"g4_earlystop_{tag}", x=x, y=y, eps=np.float64(eps), n_iter=np.int64(n_iter),
+            n_forward=np.int64(calls[0]), x_best=xb, acc=acc, loss_best=lb, x_best_adv=xba)
+
+    # ---------------------------------------------------------------- G5 apgd_largereps (CPU RNG reproduced by seed)
+    for C, n_iter in ((5, 10), (21, 20)):
+        net = TinyConvNet(C, seed=C + 50)
+        g = torch.Generator().manual_seed(2000 + C)
+        x = torch.rand(2, 3, 16, 16, generator=g)
+        y = make_labels(net, x, ignore_frac=0.03, flip_frac=0.1, seed=C + 1)
+        w = torch.tensor(VOC_WTS) if C == 21 else torch.rand(C, generator=g)
+        for loss in ("mask-ce-avg", "mask-ce-bal", "js-avg"):
+            torch.manual_seed(4321)
+            with contextlib.redirect_stdout(io.StringIO()):
+                xa, _, acc = A.apgd_largereps(net, x.clone(), y, w, norm="Linf", eps=4.0 / 255, n_iter=n_iter,
+                                              n_restarts=1, use_rs=True, loss=loss, verbose=False,
+                                              track_loss="ce-avg", log_path=None, num_classes=C,
+                                              early_stop=True)
+            npz(f"g5_largereps_C{C}_{loss}", x=x, y=y, w=w, eps=np.float64(4.0 / 255), n_iter=np.int64(n_iter),
+                seed=np.int64(4321), x_adv=xa, acc=acc)
+
+    # ---------------------------------------------------------------- G6 PIR-AT inner PGD
+    net = TinyConvNet(21, seed=9)
+    g = torch.Generator().manual_seed(3000)
+    x = torch.rand(2, 3, 16, 16, generator=g)
+    y = make_labels(net, x, ignore_frac=0.0, flip_frac=0.1, seed=4)
+    torch.manual_seed(99)
+    xa1, logits1, _ = V.Pgd_Attack_1(epsilon=4.0 / 255, alpha=1e-2, num_iter=5, los="pgd").adv_attack(net, x, y)
+    xa2, _, _ = V.Pgd_Attack(eps=4.0 / 255, alpha=1e-2, num_iter=5, los="mask-ce-avg").adv_attack(net, x, y)
+    xa3, _, _ = V.Pgd_Attack(eps=4.0 / 255, alpha=1e-2, num_iter=5, los="js-avg").adv_attack(net, x, y)
+    npz("g6_pgd", x=x, y=y, seed=np.int64(99), x_adv_1=xa1, logits_1=logits1.detach(), x_adv_mce=xa2, x_adv_js=xa3)
+
+    # ---------------------------------------------------------------- G7 evalSEA
+    import tools.worse_only as W
+
+    class _DS(torch.utils.data.Dataset):
+        def __init__(self, targets):
+            self.t = targets
+
+        def __len__(self):
+            return self.t.shape[0]
+
+        def __getitem__(self, i):
+            return torch.zeros(1), self.t[i], str(i)
+
+    for tag, (N, C, bs, absent) in {"a": (12, 5, 4, False), "b": (16, 21, 8, True), "c": (10, 5, 4, False)}.items():
+        g = torch.Generator().manual_seed(500 + N + C)
+        tgt = torch.randint(0, C, (N, 12, 12), generator=g)
+        if absent:
+            tgt[tgt == C - 1] = 0
+        preds = []
+        for a in range(3):
+            p = tgt.clone()
+            flip = torch.rand(p.shape, generator=g) < (0.25 + 0.1 * a)
+            p[flip] = torch.randint(0, C - (1 if absent else 0), (int(flip.sum()),), generator=g)
+            preds.append(p)
+        if tag == "c":
+            tgt[torch.rand(tgt.shape, generator=g) < 0.05] = -1
+        with tempfile.TemporaryDirectory() as td:
+            os.makedirs(os.path.join(td, "test_results"))
+            sd = {"seed": 225, "worst_Acc": 0, "worst_Acc_indiv": 0, "final_miou": 0, "loss-wise_miou": []}
+            ev = W.evalSEA(_DS(tgt), [p.clone() for p in preds], 4.0, C, "SEA_test", td, sd, "m")
+            with contextlib.redirect_stdout(io.StringIO()):
+                ev.worse_case_eval(bs=bs, n_batches=-1)
+                random.seed(225)
+                ev.worst_case_miou()
+            st = torch.load(os.path.join(td, "test_results", "stats_SEA_test_4.0.pt"))
+        npz(f"g7_evalsea_{tag}", preds=torch.stack(preds), targets=tgt, n_cls=np.int64(C), bs=np.int64(bs),
+            worst_Acc=np.float64(ev.saveDict["worst_Acc"]), worst_Acc_indiv=ev.saveDict["worst_Acc_indiv"],
+            final_miou=np.float64(ev.saveDict["final_miou"]), ints=st["run_int_imwise"],
+            unions=st["run_union_imwise"])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,158 @@
+"""Pins the CPU oracle (oracle/sea_oracle.py) to golden vectors produced by the real reference
+(oracle/gen_goldens.py, run in the build container).  CPU only; runs everywhere."""
+import glob
+import os
+import random
+
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+from oracle import sea_oracle as O
+from oracle.tiny_models import PointwiseNet, TinyConvNet
+
+LOSSES = ("mask-ce-avg", "mask-ce-bal", "js-avg")
+
+
+@pytest.mark.parametrize("C", [5, 21, 151])
+def test_g1_losses_and_grads(C):
+    g = load_golden(f"g1_losses_C{C}")
+    logits, y, w = g["logits"], g["y"], g["w"]
+    mask_bg = (y != -1).float()
+    for name, mode in (("mask-ce-avg", 0), ("mask-ce-bal", 1), ("js-avg", 2), ("ce", 3)):
+        key = name.replace("-", "_")
+        px = O.pixel_losses(logits, y, w, mode)
+        torch.testing.assert_close(px, g[key + "_px"], rtol=2e-5, atol=2e-6)
+        img = O.pixel_to_img_loss(px, mask_bg)
+        torch.testing.assert_close(img, g[key + "_img"], rtol=1e-5, atol=1e-7)
+        gr = O.pixel_loss_grad(logits, y, w, mode)
+        torch.testing.assert_close(gr, g[key + "_grad"], rtol=1e-4, atol=2e-8)  # grads are O(1/HW)=4e-3; JS autograd in the reference cancels
+    st0 = O.loss_fwd_bwd(logits, y, w, 0, 3, with_grad=False, ignored_correct=False)
+    st1 = O.loss_fwd_bwd(logits, y, w, 0, 3, with_grad=False, ignored_correct=True)
+    assert torch.equal(st0["pred"], g["pred"])
+    assert torch.equal(st0["acc_img"], g["acc_step0"])
+    assert torch.equal(st1["acc_img"], g["acc_loop"])
+    torch.testing.assert_close(st1["track_img"], g["ce_img"], rtol=1e-5, atol=1e-7)
+
+
+def test_g1_argmax_first_max():
+    g = load_golden("g1_argmax_ties")
+    assert torch.equal(O.argmax_first(g["z"].view(3, 4, 1, 1)).view(3), g["arg"])
+
+
+def test_g2_linf_bit_exact():
+    g = load_golden("g2_linf")
+    for ci in range(5):
+        p = lambda k: g[f"c{ci}_{k}"]  # noqa: E731
+        out = O.apgd_linf_step(p("x"), p("x_adv"), p("x_old"), p("grad"), p("step"), p("eps"), p("a"))
+        assert torch.equal(out, p("out"))
+        assert torch.equal(O.linf_random_start(p("x"), p("u"), p("eps")), p("rs"))
+        assert torch.equal(O.linf_project(p("zz"), p("x"), p("eps")), p("proj"))
+        assert torch.equal(O.pgd_linf_step(p("x"), p("delta"), p("grad"), p("alpha"), p("eps")), p("delta_out"))
+
+
+@pytest.mark.parametrize("C", [5, 21])
+def test_g3_counts_and_metrics(C):
+    g = load_golden(f"g3_counts_C{C}")
+    pred, y = g["pred"].clone(), g["y"]
+    m_acc, a_acc, m_iou = O.compute_iou_acc(pred, y, C)
+    assert torch.equal(pred, g["pred_after"])  # in-place ignore overwrite (attacker.py:20)
+    assert m_acc.item() == pytest.approx(g["m_acc"], rel=1e-6)
+    assert a_acc.item() == pytest.approx(g["a_acc"], rel=1e-6)
+    assert m_iou.item() == pytest.approx(g["m_iou"], rel=1e-6)
+    hist = O.confusion_matrix(g["pred"], y, C)
+    assert torch.equal(hist.float(), g["hist"])
+    m = O.metrics_from_hist(hist)
+    import numpy as np
+    np.testing.assert_allclose(np.array(m["ious"]), g["ious"].numpy(), rtol=0, atol=1e-9, equal_nan=True)
+    np.testing.assert_allclose(np.array(m["acc"]), g["acc"].numpy(), rtol=0, atol=1e-9, equal_nan=True)
+    np.testing.assert_allclose(np.array(m["f1"]), g["f1"].numpy(), rtol=0, atol=1e-9, equal_nan=True)
+    assert m["miou"] == g["miou"] and m["macc"] == g["macc"] and m["mf1"] == g["mf1"]
+    assert float(m["aacc"]) == pytest.approx(g["aacc"])
+    # counts are consistent with the confusion matrix
+    inter, pc, tc = O.class_counts(g["pred"], y, C)
+    assert torch.equal(inter, hist.diag()) and torch.equal(tc, hist.sum(1)) and torch.equal(pc, hist.sum(0))
+
+
+def _g4_files():
+    return sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "g4_apgd_*_C*.npz")))
+
+
+@pytest.mark.parametrize("name", _g4_files())
+def test_g4_apgd_train_trajectory(name):
+    g = load_golden(name)
+    _, _, netname, Cs, loss, n = name.split("_")
+    C, n_iter = int(Cs[1:]), int(n)
+    net = (TinyConvNet if netname == "conv" else PointwiseNet)(C, seed=C)
+    xb, acc, lb, xba = O.apgd_train(net, g["x"], g["y"], "Linf", g["eps"], n_iter=n_iter, use_rs=False, loss=loss,
+                                    track_loss="ce-avg", x_init=g["x_init"], weights=g["w"], early_stop=True)
+    assert torch.equal(acc, g["acc"])
+    torch.testing.assert_close(lb, g["loss_best"], rtol=1e-5, atol=1e-6)
+    # trajectories are sign-sensitive; demand agreement on all but a vanishing fraction of values
+    for got, ref in ((xb, g["x_best"]), (xba, g["x_best_adv"])):
+        frac = ((got - ref).abs() > 1e-6).float().mean().item()
+        assert frac <= 0.002, frac
+
+
+EARLY = {
+    "a": (TinyConvNet, dict(seed=4, gain=3.0), "js-avg"),
+    "b": (TinyConvNet, dict(seed=5, gain=3.0), "mask-ce-avg"),
+    "c": (PointwiseNet, dict(seed=3, gain=8.0, bias=0.0), "mask-ce-avg"),
+}
+
+
+@pytest.mark.parametrize("tag", sorted(EARLY))
+def test_g4_early_stop(tag):
+    g = load_golden(f"g4_earlystop_{tag}")
+    Net, kw, loss = EARLY[tag]
+    net = Net(5, **kw)
+    tr = {}
+    xb, acc, lb, xba = O.apgd_train(net, g["x"], g["y"], "Linf", g["eps"], n_iter=int(g["n_iter"]), loss=loss,
+                                    track_loss="ce-avg", early_stop=True, trace=tr)
+    # the reference ran 1 + n_done forwards: same number of loop iterations before the break
+    assert tr["n_done"] + 1 == int(g["n_forward"]) and tr["n_done"] < int(g["n_iter"])
+    assert acc.sum() == 0 and torch.equal(acc, g["acc"])
+    torch.testing.assert_close(lb, g["loss_best"], rtol=1e-5, atol=1e-6)
+    for got, ref in ((xb, g["x_best"]), (xba, g["x_best_adv"])):
+        assert ((got - ref).abs() > 1e-6).float().mean().item() <= 0.01
+
+
+@pytest.mark.parametrize("C,loss", [(c, l) for c in (5, 21) for l in LOSSES])
+def test_g5_largereps(C, loss):
+    g = load_golden(f"g5_largereps_C{C}_{loss}")
+    net = TinyConvNet(C, seed=C + 50)
+    torch.manual_seed(int(g["seed"]))
+    xa, _, acc = O.apgd_largereps(net, g["x"].clone(), g["y"], g["w"], eps=g["eps"], n_iter=int(g["n_iter"]),
+                                  use_rs=True, loss=loss, track_loss="ce-avg", early_stop=True)
+    assert torch.equal(acc, g["acc"])
+    frac = ((xa - g["x_adv"]).abs() > 1e-6).float().mean().item()
+    assert frac <= 0.002, frac
+    assert (xa - g["x"]).abs().max() <= g["eps"] + 1e-7
+
+
+def test_g6_pgd():
+    g = load_golden("g6_pgd")
+    net = TinyConvNet(21, seed=9)
+    torch.manual_seed(int(g["seed"]))
+    xa1, logits1 = O.pgd_attack_1(net, g["x"], g["y"], epsilon=4.0 / 255, alpha=1e-2, num_iter=5, los="pgd")
+    frac = ((xa1 - g["x_adv_1"]).abs() > 1e-6).float().mean().item()
+    assert frac <= 0.002
+    torch.testing.assert_close(logits1, g["logits_1"], rtol=1e-3, atol=1e-3)
+    for los, key in (("mask-ce-avg", "x_adv_mce"), ("js-avg", "x_adv_js")):
+        xa = O.pgd_attack(net, g["x"], g["y"], eps=4.0 / 255, alpha=1e-2, num_iter=5, los=los)
+        frac = ((xa - g[key]).abs() > 1e-6).float().mean().item()
+        assert frac <= 0.002, (los, frac)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_g7_evalsea(tag):
+    g = load_golden(f"g7_evalsea_{tag}")
+    C, bs = int(g["n_cls"]), int(g["bs"])
+    preds, tgt = g["preds"], g["targets"]
+    wa, indiv, _ = O.worst_case_acc(preds, tgt, C, bs=bs)
+    assert wa == pytest.approx(g["worst_Acc"], rel=1e-6)
+    torch.testing.assert_close(indiv, g["worst_Acc_indiv"], rtol=1e-6, atol=0)
+    ints, unis = O.per_image_tables(preds, tgt, C)
+    assert torch.equal(ints, g["ints"]) and torch.equal(unis, g["unions"])
+    final, sel, rounds = O.worst_case_miou(ints, unis, rng=random.Random(225))
+    assert final == g["final_miou"]  # exact: same float64 arithmetic, same shuffle stream

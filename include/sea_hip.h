@@ -1,0 +1,183 @@
+/*
+ * sea_hip.h - C ABI of libsea_hip.so: the MI355X (gfx950) attack-side hot path of
+ * SEA (Segmentation Ensemble Attack) evaluation and the PIR-AT inner PGD loop.
+ *
+ * The reference (nmndeep/Robust-Segmentation) is 100 % Python: it has no FFI, its "interface" for
+ * this path is the ATen op sequences inside semseg/attacker.py, semseg/val.py, semseg/metrics.py
+ * and tools/worse_only.py.  Every entry point below replaces one such sequence and cites it
+ * (paths relative to the reference repo root).  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; all device pointers are HBM addresses on the
+ *     current HIP device; the caller allocates and owns every buffer; the library keeps no global
+ *     state and never allocates, frees or synchronises -> re-entrant per stream, graph-capturable.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).  All device
+ *     work is stream ordered and asynchronous.
+ *   - return value: 0 on success, otherwise a hipError_t value (1 = invalid argument).  Nothing
+ *     throws across the ABI.
+ *   - tensors are dense, NCHW ("planes") unless a layout argument says otherwise.
+ *   - labels: any of int64 / int32 / int16 / uint8 (y_bytes = 8/4/2/1); the ignore label is -1
+ *     (255 for uint8).  Labels outside [0,C) are treated as ignored.
+ *   - loss modes: 0 mask-ce-avg, 1 mask-ce-bal, 2 js-avg, 3 ce / ce-avg.
+ *   - logits dtype: 0 float32, 1 bfloat16, 2 float16 (dlogits has the same dtype and layout).
+ */
+#ifndef SEA_HIP_H
+#define SEA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEA_MODE_MASK_CE 0
+#define SEA_MODE_MASK_CE_BAL 1
+#define SEA_MODE_JS 2
+#define SEA_MODE_CE 3
+
+#define SEA_DTYPE_F32 0
+#define SEA_DTYPE_BF16 1
+#define SEA_DTYPE_F16 2
+
+#define SEA_LAYOUT_NCHW 0
+#define SEA_LAYOUT_NHWC 1
+
+/* library / build identification */
+int sea_abi_version(void);
+const char* sea_build_info(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * K1  APGD L-inf step with momentum.            replaces semseg/attacker.py:389-410, 456
+ *   g2 = x_adv - x_old ; z = x_adv + step[b]*sign(grad) ; z = clip(clip(z, x-eps, x+eps), 0, 1)
+ *   z = x_adv + (z - x_adv)*a + g2*(1-a)        ; out = clip(clip(z, x-eps, x+eps), 0, 1)
+ * Bit-exact w.r.t. the float32 op sequence of the reference.  `out` must not alias an input.
+ * n_per_img = 3*H*W elements per image; step_b has B entries.
+ */
+int sea_apgd_linf_step(const float* x, const float* x_adv, const float* x_old, const float* grad,
+                       const float* step_b, float eps, float a, float* out, int B,
+                       int64_t n_per_img, void* stream);
+
+/* K5a random start: out = clip(x + eps*(2u-1), 0, 1).          semseg/attacker.py:293-294, 308 */
+int sea_linf_random_start(const float* x, const float* u, float eps, float* out, int64_t n,
+                          void* stream);
+/* K5b stage re-projection: out = clip(x + clip(z-x,-eps,eps), 0, 1). semseg/attacker.py:683-690 */
+int sea_linf_project(const float* z, const float* x, float eps, float* out, int64_t n,
+                     void* stream);
+
+/* K6  PIR-AT PGD step on the perturbation.                      semseg/val.py:209-214 (168-172)
+ *   d = delta + alpha*sign(grad) ; d = clip(X+d,0,1) - X ; delta_out = clip(d,-eps,eps)
+ * If x_in_out != NULL it also receives the next model input: X+delta_out (clamp_input=0,
+ * Pgd_Attack_1, val.py:200) or clip(X+delta_out,0,1) (clamp_input=1, Pgd_Attack val.py:150 and the
+ * final x_adv of both, val.py:177, 217).  delta_out may alias delta. */
+int sea_pgd_linf_step(const float* X, const float* delta, const float* grad, float alpha,
+                      float eps, float* delta_out, float* x_in_out, int clamp_input, int64_t n,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K2  fused per-pixel loss forward + logit gradient + tracking loss + accuracy + argmax.
+ * replaces  masked_cross_entropy / _balanced / js_loss (semseg/attacker.py:143-173, 187-234),
+ *           pixel_to_img_loss (237-240), the autograd of lines 347-350 / 462-469 down to the logits,
+ *           the tracking loss (359-361, 473-475) and accuracy / argmax (370-373, 485-495);
+ *           also the val.py losses (semseg/val.py:104-127) through `mode` + `grad_scale`.
+ *
+ *   logits   (B,C,H,W) [layout 0] or (B,H,W,C) [layout 1], dtype per `dtype`
+ *   y        (B,H,W) labels, y_bytes wide
+ *   w        (C) float32 class weights, required for mode/track_mode 1, else may be NULL
+ *   grad_scale  upstream gradient per valid pixel (1/(H*W) for the per-image mean of the reference)
+ *   dlogits  same shape/dtype/layout as logits, or NULL to skip the gradient (last APGD step,
+ *            attacker.py:467, and clean/adversarial evaluation)
+ *   pred     (B,H,W) argmax map (first maximum wins), pred_bytes wide (8/4/2/1) or NULL
+ *   loss_px  (B,H,W) float32 per-pixel attack loss (reduction="none" of the reference functions) or NULL
+ *   workspace  sea_loss_workspace_bytes(B,HW) bytes of scratch
+ *   loss_sum / track_sum (B) float32: SUM over the image's pixels of the attack / tracking loss
+ *            (the caller divides by H*W; attacker.py:240 divides by all pixels incl. ignored)
+ *   n_correct (B) int32: #valid pixels with argmax == label
+ * Reductions are two-stage with a fixed order (no float atomics): results are run-to-run
+ * deterministic.
+ */
+size_t sea_loss_workspace_bytes(int B, int64_t HW);
+int sea_loss_fwd_bwd(const void* logits, int dtype, int layout, const void* y, int y_bytes,
+                     const float* w, int mode, int track_mode, int B, int C, int64_t HW,
+                     float grad_scale, void* dlogits, void* pred, int pred_bytes, float* loss_px,
+                     void* workspace, size_t workspace_bytes, float* loss_sum, float* track_sum,
+                     int32_t* n_correct, void* stream);
+/* Benchmark hook: identical, but pins the pixels-per-lane (1/2/4, 0 = heuristic) of the register kernel. */
+int sea_loss_fwd_bwd_tuned(const void* logits, int dtype, int layout, const void* y, int y_bytes,
+                           const float* w, int mode, int track_mode, int B, int C, int64_t HW,
+                           float grad_scale, void* dlogits, void* pred, int pred_bytes, float* loss_px,
+                           void* workspace, size_t workspace_bytes, float* loss_sum, float* track_sum,
+                           int32_t* n_correct, void* stream, int force_vec);
+
+/* ------------------------------------------------------------------------------------------------
+ * K3  per-class integer statistics.
+ * sea_class_counts replaces compute_iou_acc's loops (semseg/attacker.py:14-45), eval_performance
+ * (tools/infer.py:90-116) and update_fn / update_fn_indiv (tools/worse_only.py:30-66).
+ *   inter[c] += #{pred==y==c}; tgt_cnt[c] += #{y==c}; pred_cnt[c] += #{pred==c}
+ *   mask_pred=1: pixels with ignored label do not count in pred_cnt (attacker.py:20, infer.py:90);
+ *   mask_pred=0: they do (worse_only.py:42, 62).   union = tgt_cnt + pred_cnt - inter.
+ *   per_image=1: outputs are (B,C), else (C).  Outputs are int64 and are ACCUMULATED into.
+ * sea_confusion replaces Metrics.update's bincount (semseg/metrics.py:27-33): hist[t*C+p] += 1 for
+ * every pixel whose label is valid.
+ * Where only the argmax is needed (infer.py:88, metrics.py:28) call sea_loss_fwd_bwd with dlogits=NULL.
+ */
+int sea_class_counts(const void* pred, int pred_bytes, const void* y, int y_bytes, int B, int C,
+                     int64_t HW, int mask_pred, int per_image, int64_t* inter, int64_t* pred_cnt,
+                     int64_t* tgt_cnt, void* stream);
+int sea_confusion(const void* pred, int pred_bytes, const void* y, int y_bytes, int64_t n, int C,
+                  int64_t* hist, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K4 + K7  device-resident APGD bookkeeping (no host round trip).
+ *
+ * sea_apgd_track: one tiny launch per iteration.  replaces semseg/attacker.py:370-383 (init=1),
+ *   485-495 (best-adv tracking), 520-526 (best-loss tracking), 243-248 + 528-551 (oscillation
+ *   check and step halving) and 568-569 (early stop, as a device flag).
+ *     loss_sum/track_sum/n_correct  outputs of K2 for this iterate;  n_ignored (B) #ignored pixels
+ *     iter      loop index i (ignored when init=1);  n_iter rows in loss_steps
+ *     check_k   0, or the window k when this iteration is a checkpoint (schedule is data
+ *               independent, attacker.py:528-551, so the host knows it)
+ *   state (all (B) unless noted, updated in place):
+ *     acc_cnt int32 (best = lowest #correct incl. ignored-as-correct), acc float = acc_cnt/HW,
+ *     loss_best, loss_best_last, reduced_last, step (float32), loss_steps (n_iter,B) float32,
+ *     flags uint8 (3,B): [0] copy x_adv->x_best_adv & pred->pred_best   (avg_acc <= acc)
+ *                        [1] copy x_adv->x_best, grad->grad_best        (loss  >  loss_best)
+ *                        [2] restart: x_adv<-x_best, grad<-grad_best    (step halved)
+ *     done int32[1]: set to 1 when early_stop and every image has zero accuracy; once set, later
+ *                    calls clear all flags and change nothing (the reference would have left the loop).
+ * sea_select_copy: the conditional bulk copies selected by `flags` (attacker.py:494-495, 523-524,
+ *   547-548), one launch.  pred/pred_best may be NULL.
+ */
+int sea_apgd_track(const float* loss_sum, const float* track_sum, const int32_t* n_correct,
+                   const int32_t* n_ignored, int B, int64_t HW, int iter, int n_iter, int check_k,
+                   int early_stop, int init, int32_t* acc_cnt, float* acc, float* loss_best,
+                   float* loss_best_last, float* reduced_last, float* step, float* loss_steps,
+                   uint8_t* flags, int32_t* done, void* stream);
+int sea_select_copy(const uint8_t* flags, float* x_adv, float* grad, float* x_best,
+                    float* grad_best, float* x_best_adv, const void* pred, void* pred_best,
+                    int pred_bytes, int B, int64_t n_per_img, int64_t HW, void* stream);
+
+/* sea_count_ignored: n_ignored[b] = #{y[b] ignored}  (attacker.py:302-306, 489). */
+int sea_count_ignored(const void* y, int y_bytes, int B, int64_t HW, int32_t* n_ignored,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K8 + K9  worst-case bookkeeping over the attacks (HOST code, sequential by nature).
+ * sea_worst_miou_greedy replaces evalSEA.worst_case_miou's greedy (tools/worse_only.py:279-334)
+ * including _compute_miou / _compute_miou_subtraction (69-93) and Python's random.shuffle stream:
+ *   ints/unions (A,N,C) float32 per-image tables (worse_only.py:200-234)
+ *   mt_state    625 uint32: CPython `random.getstate()[1]` (624 words + position); advanced in
+ *               place exactly as `random.shuffle` would, so the caller can `random.setstate` back
+ *   outputs: *miou (fraction), selected (N) attack index per image, *rounds_run.
+ * Arithmetic follows the reference bit for bit (float32 table differences, float32 rounding of the
+ * running totals, float64 quotients, exactly rounded mean as in statistics.mean).
+ */
+int sea_worst_miou_greedy(const float* ints, const float* unions, int A, int N, int C,
+                          uint32_t* mt_state, int n_rounds, double* miou, int32_t* selected,
+                          int32_t* rounds_run);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEA_HIP_H */

@@ -1,0 +1,658 @@
+// K2: fused per-pixel SEA loss forward + logit gradient + tracking loss + accuracy + argmax.
+//
+// Roofline: HBM.  Algorithmic bytes per pixel (fp32, with gradient): 2*C*4 (read logits, write
+// dlogits) + label + pred.  One pass: every logit is loaded from HBM exactly once, kept in
+// registers (class vector of a pixel = CPAD registers per lane, VEC pixels per lane), and its
+// gradient is written exactly once.
+//
+// Layout NCHW ("class planes"): lane l of a wave owns VEC consecutive pixels; for every class c the
+// wave reads one contiguous 64*VEC*4-byte segment of plane c -> perfectly coalesced
+// global_load_dwordx4 (VEC=4) with C independent loads in flight per lane (latency hiding by ILP,
+// no LDS needed because there is no reuse across lanes: the class reduction is within a lane).
+//
+// Per-image sums (loss, tracking loss, #correct) are reduced wave -> block with shuffles + LDS and
+// written as one record per block; a second tiny kernel sums the records of an image in a fixed
+// order in double precision.  No float atomics => bitwise run-to-run determinism.
+#include "sea_common.h"
+
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+
+namespace sea {
+
+constexpr float kLn2 = 0.69314718055994530942f;
+
+struct __attribute__((aligned(16))) BlockPartial {
+  float loss, track;
+  int n_correct, pad;
+};
+
+// ---- element conversion -------------------------------------------------------------------
+// logits travel as raw bits (float, or 16-bit patterns for bf16/f16) so that vector loads/stores can
+// use address-space-qualified ext-vector types.
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+  using raw = float;
+  static __device__ __forceinline__ float to_f(raw v) { return v; }
+  static __device__ __forceinline__ raw from_f(float v) { return v; }
+};
+template <>
+struct Elem<__hip_bfloat16> {
+  using raw = unsigned short;
+  static __device__ __forceinline__ float to_f(raw v) { return __uint_as_float(((unsigned int)v) << 16); }
+  static __device__ __forceinline__ raw from_f(float v) {
+    const __hip_bfloat16 h = __float2bfloat16(v);  // round-to-nearest-even, NaN preserving
+    return __builtin_bit_cast(unsigned short, h);
+  }
+};
+template <>
+struct Elem<__half> {
+  using raw = unsigned short;
+  static __device__ __forceinline__ float to_f(raw v) { return __half2float(__ushort_as_half(v)); }
+  static __device__ __forceinline__ raw from_f(float v) { return __half_as_ushort(__float2half(v)); }
+};
+
+template <typename R, int VEC>
+struct RawVec {
+  typedef R type __attribute__((ext_vector_type(VEC)));
+};
+template <typename R>
+struct RawVec<R, 1> {
+  typedef R type;
+};
+template <typename R, int VEC>
+__device__ __forceinline__ R vec_get(const typename RawVec<R, VEC>::type& p, int v) {
+  if constexpr (VEC == 1)
+    return p;
+  else
+    return p[v];
+}
+template <typename R, int VEC>
+__device__ __forceinline__ void vec_set(typename RawVec<R, VEC>::type& p, int v, R x) {
+  if constexpr (VEC == 1)
+    p = x;
+  else
+    p[v] = x;
+}
+
+template <typename T>
+using gptr = const __attribute__((address_space(1))) T*;
+template <typename T>
+using gptr_w = __attribute__((address_space(1))) T*;
+
+// per-pixel loss value for a mode; ce = lse - z_y, logp = z_y - lse (<= 0)
+__device__ __forceinline__ float loss_value(int mode, bool valid, bool correct, float ce, float logp, float py,
+                                            float l1p, float wy) {
+  switch (mode) {
+    case SEA_MODE_MASK_CE: return correct ? ce : 0.f;
+    case SEA_MODE_MASK_CE_BAL: return correct ? wy * ce : 0.f;
+    case SEA_MODE_JS: return valid ? (kLn2 + 0.5f * (py * logp - (1.f + py) * l1p)) : 0.f;
+    default: return valid ? ce : 0.f;
+  }
+}
+
+// gradient coefficient K: d loss / d z_c = K * (p_c - [c == y])   
+__device__ __forceinline__ float grad_coef(int mode, bool valid, bool correct, float logp, float py, float l1p,
+                                           float wy) {
+  if (mode == SEA_MODE_JS) return valid ? (-0.5f * (logp - l1p) * py) : 0.f;
+  if (mode == SEA_MODE_CE) return valid ? 1.f : 0.f;
+  return correct ? wy : 0.f;
+}
+
+// block reduction of the three per-thread sums and record write (fixed order, deterministic)
+__device__ __forceinline__ void block_reduce_store(float ls, float ts, int nc, BlockPartial* dst) {
+  __shared__ float s_l[4], s_t[4];
+  __shared__ int s_n[4];
+  ls = wave_sum(ls);
+  ts = wave_sum(ts);
+  nc = wave_sum_i(nc);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+    s_l[wave] = ls;
+    s_t[wave] = ts;
+    s_n[wave] = nc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    BlockPartial p;
+    p.loss = (s_l[0] + s_l[1]) + (s_l[2] + s_l[3]);
+    p.track = (s_t[0] + s_t[1]) + (s_t[2] + s_t[3]);
+    p.n_correct = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+    p.pad = 0;
+    *dst = p;
+  }
+}
+
+// ---- NCHW, class vector in registers ---------------------------------------------------------
+// grid = (tiles per image, B); block = 256 threads; tile = 256*VEC consecutive pixels of one image.
+// CPAD = number of class registers; EXACT means C == CPAD (no per-class guards at all).
+//
+// Codegen notes (each one was a measured register-file problem):
+//  * planes are addressed as ONE wave-uniform 64-bit pointer (SGPR pair, global address space)
+//    advanced by HW per class, plus a 32-bit per-lane byte offset -> `global_load_dwordx4 v, v_off,
+//    s[ptr:ptr+1]`.  The empty asm keeps the running pointer opaque so that the compiler does not
+//    materialise C separate 64-bit plane addresses.
+//  * argmax is computed as max-chain followed by a descending "first index equal to the max" scan;
+//    the textbook `if (z > m) { m = z; arg = c; }` makes the compiler keep C 64-bit lane masks alive
+//    (one per compare) and spill them.
+//  * the label compares of the gradient pass use an opaque copy of the label so they are not CSE'd
+//    with those of the z_y select (same reason).
+template <typename T, int CPAD, int VEC, bool GRAD, bool EXACT>
+__global__ __launch_bounds__(256) void loss_nchw_reg(const T* __restrict__ logits, const void* __restrict__ y,
+                                                     int y_bytes, const float* __restrict__ w, int mode,
+                                                     int track_mode, int C, int64_t HW, float gscale,
+                                                     T* __restrict__ dlogits, void* __restrict__ pred,
+                                                     int pred_bytes, float* __restrict__ loss_px,
+    BlockPartial* __restrict__ partials) {
+  using R = typename Elem<T>::raw;
+  using P = typename RawVec<R, VEC>::type;
+  const int b = blockIdx.y;
+  const int64_t px0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC;
+  const bool active = px0 < HW;  // HW % VEC == 0 is guaranteed by the launcher
+  const uint32_t lane_off = (uint32_t)(threadIdx.x * VEC * sizeof(T));
+  if (EXACT) C = CPAD;
+
+  float z[CPAD][VEC];
+  int lab[VEC];
+#pragma unroll
+  for (int c = 0; c < CPAD; ++c)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) z[c][v] = -INFINITY;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) lab[v] = -1;
+
+  if (active) {
+    // labels first: their latency hides under the C plane loads issued right after
+    load_labels<VEC>(y, y_bytes, (int64_t)b * HW + px0, lab);
+    gptr<char> plane = (gptr<char>)(logits + (int64_t)b * C * HW + (int64_t)blockIdx.x * 256 * VEC);
+    const int64_t plane_bytes = HW * (int64_t)sizeof(T);
+#pragma unroll
+    for (int c = 0; c < CPAD; ++c) {
+      if (EXACT || c < C) {
+        const P p = *reinterpret_cast<gptr<P>>(plane + lane_off);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) z[c][v] = Elem<T>::to_f(vec_get<R, VEC>(p, v));
+      }
+      plane += plane_bytes;
+      asm volatile("" : "+s"(plane));
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) lab[v] = (lab[v] < 0 || lab[v] >= C) ? -1 : lab[v];
+  }
+
+  float lsum = 0.f, tsum = 0.f;
+  int ncorr = 0;
+  float K[VEC];  // gradient = K * (p_c - [c == y])
+  float A[VEC];  // K / sum_exp
+  int amax[VEC];
+  float lpx[VEC];
+
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    float m = z[0][v];
+#pragma unroll
+    for (int c = 1; c < CPAD; ++c) m = fmaxf(m, z[c][v]);
+    // first index attaining the maximum (torch.max tie-break): descending scan, last write wins
+    int arg = 0;
+    float zy = 0.f;
+#pragma unroll
+    for (int c = CPAD - 1; c >= 0; --c) {
+      const float zc = z[c][v];
+      arg = (zc == m) ? c : arg;
+      zy = (lab[v] == c) ? zc : zy;
+    }
+    // Order fence (no instruction): the exp pass below overwrites z in place, so the scan above must
+    // be complete first; without it the compiler runs exp early into fresh registers and keeps
+    // BOTH z and exp(z-m) alive (2x the register file, half the occupancy).
+    asm volatile("" : "+v"(m) : "v"(arg), "v"(zy));
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CPAD; ++c) {
+      const float e = __expf(z[c][v] - m);  // padded classes: exp(-inf) = 0
+      z[c][v] = e;
+      s += e;
+    }
+    const bool valid = active && lab[v] >= 0;
+    const bool correct = valid && (arg == lab[v]);
+    const float lse = m + __logf(s);
+    const float ce = lse - zy;
+    const float logp = zy - lse;
+    const bool need_js = (mode == SEA_MODE_JS) || (track_mode == SEA_MODE_JS);
+    float py = 0.f, l1p = 0.f;
+    if (need_js) {
+      py = __expf(logp);
+      l1p = __logf(1.f + py);
+    }
+    const bool need_w = (mode == SEA_MODE_MASK_CE_BAL) || (track_mode == SEA_MODE_MASK_CE_BAL);
+    const float wy = (need_w && valid) ? w[lab[v]] : 1.f;
+    const float lv = loss_value(mode, valid, correct, ce, logp, py, l1p, wy);
+    lsum += lv;
+    lpx[v] = lv;
+    tsum += (track_mode == mode) ? lv : loss_value(track_mode, valid, correct, ce, logp, py, l1p, wy);
+    ncorr += correct ? 1 : 0;
+    amax[v] = arg;
+    if (GRAD) {
+      K[v] = grad_coef(mode, valid, correct, logp, py, l1p, wy) * gscale;
+      A[v] = K[v] / s;
+    }
+  }
+
+  if (active) {
+    if (pred != nullptr) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) store_index_rt(pred, pred_bytes, (int64_t)b * HW + px0 + v, amax[v]);
+    }
+    if (loss_px != nullptr) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) loss_px[(int64_t)b * HW + px0 + v] = lpx[v];
+    }
+    if (GRAD) {
+      gptr_w<char> gplane = (gptr_w<char>)(dlogits + (int64_t)b * C * HW + (int64_t)blockIdx.x * 256 * VEC);
+      const int64_t plane_bytes = HW * (int64_t)sizeof(T);
+      int lab2[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        lab2[v] = lab[v];
+        asm volatile("" : "+v"(lab2[v]));
+      }
+#pragma unroll
+      for (int c = 0; c < CPAD; ++c) {
+        if (EXACT || c < C) {
+          P p;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            // K*(e_c/s - [c==y]) = A*e_c - (c==y ? K : 0)
+            const float g = A[v] * z[c][v];
+            vec_set<R, VEC>(p, v, Elem<T>::from_f((lab2[v] == c) ? g - K[v] : g));
+          }
+          *reinterpret_cast<gptr_w<P>>(gplane + lane_off) = p;
+        }
+        gplane += plane_bytes;
+        asm volatile("" : "+s"(gplane));
+      }
+    }
+  }
+  block_reduce_store(lsum, tsum, ncorr, partials + (int64_t)b * gridDim.x + blockIdx.x);
+}
+
+// ---- NCHW, any C: two passes over the class planes (second pass re-reads; used only when the class
+// vector does not fit the register file) ---------------------------------------------------------------
+template <typename T, bool GRAD>
+__global__ __launch_bounds__(256) void loss_nchw_stream(const T* __restrict__ logits, const void* __restrict__ y,
+                                                        int y_bytes, const float* __restrict__ w, int mode,
+                                                        int track_mode, int C, int64_t HW, float gscale,
+                                                        T* __restrict__ dlogits, void* __restrict__ pred,
+                                                        int pred_bytes, float* __restrict__ loss_px,
+    BlockPartial* __restrict__ partials) {
+  const int b = blockIdx.y;
+  const int64_t px = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool active = px < HW;
+  using R = typename Elem<T>::raw;
+  const R* lbase = reinterpret_cast<const R*>(logits) + (int64_t)b * C * HW + px;
+  float lsum = 0.f, tsum = 0.f;
+  int ncorr = 0;
+  if (active) {
+    int lab = load_label_rt(y, y_bytes, (int64_t)b * HW + px);
+    lab = (lab < 0 || lab >= C) ? -1 : lab;
+    // online max / sum-exp: one read of every plane
+    float m = Elem<T>::to_f(lbase[0]);
+    int arg = 0;
+    float s = 1.f;
+    float zy = (lab == 0) ? m : 0.f;
+    for (int c = 1; c < C; ++c) {
+      const float zc = Elem<T>::to_f(lbase[(int64_t)c * HW]);
+      zy = (lab == c) ? zc : zy;
+      if (zc > m) {
+        s = s * __expf(m - zc) + 1.f;
+        m = zc;
+        arg = c;
+      } else {
+        s += __expf(zc - m);
+      }
+    }
+    const bool valid = lab >= 0;
+    const bool correct = valid && arg == lab;
+    const float lse = m + __logf(s);
+    const float ce = lse - zy, logp = zy - lse;
+    const float py = __expf(logp), l1p = __logf(1.f + py);
+    const bool need_w = (mode == SEA_MODE_MASK_CE_BAL) || (track_mode == SEA_MODE_MASK_CE_BAL);
+    const float wy = (need_w && valid) ? w[lab] : 1.f;
+    lsum = loss_value(mode, valid, correct, ce, logp, py, l1p, wy);
+    tsum = (track_mode == mode) ? lsum : loss_value(track_mode, valid, correct, ce, logp, py, l1p, wy);
+    ncorr = correct ? 1 : 0;
+    if (pred != nullptr) store_index_rt(pred, pred_bytes, (int64_t)b * HW + px, arg);
+    if (loss_px != nullptr) loss_px[(int64_t)b * HW + px] = lsum;
+    if (GRAD) {
+      const float k = grad_coef(mode, valid, correct, logp, py, l1p, wy) * gscale;
+      R* gbase = reinterpret_cast<R*>(dlogits) + (int64_t)b * C * HW + px;
+      if (k == 0.f) {
+        for (int c = 0; c < C; ++c) gbase[(int64_t)c * HW] = Elem<T>::from_f(0.f);
+      } else {
+        for (int c = 0; c < C; ++c) {
+          const float pc = __expf(Elem<T>::to_f(lbase[(int64_t)c * HW]) - lse);
+          gbase[(int64_t)c * HW] = Elem<T>::from_f(k * (pc - ((lab == c) ? 1.f : 0.f)));
+        }
+      }
+    }
+  }
+  block_reduce_store(lsum, tsum, ncorr, partials + (int64_t)b * gridDim.x + blockIdx.x);
+}
+
+// ---- NHWC (channels_last logits): the class vector of a pixel is contiguous -----------------------
+// A block stages 256 pixels x C classes through LDS with coalesced accesses, each lane then walks its
+// pixel's row in LDS (row stride padded to an odd number of dwords -> bank-conflict free).
+template <typename T, bool GRAD>
+__global__ __launch_bounds__(256) void loss_nhwc_lds(const T* __restrict__ logits, const void* __restrict__ y,
+                                                     int y_bytes, const float* __restrict__ w, int mode,
+                                                     int track_mode, int C, int CS /*row stride, floats*/,
+                                                     int64_t HW, float gscale, T* __restrict__ dlogits,
+                                                     void* __restrict__ pred, int pred_bytes, float* __restrict__ loss_px,
+                                                     BlockPartial* __restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [256][CS]
+  const int b = blockIdx.y;
+  const int64_t p0 = (int64_t)blockIdx.x * 256;
+  const int npx = (int)min((int64_t)256, HW - p0);
+  using R = typename Elem<T>::raw;
+  const R* src = reinterpret_cast<const R*>(logits) + ((int64_t)b * HW + p0) * C;
+  const int total = npx * C;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int p = i / C, c = i - p * C;
+    tile[p * CS + c] = Elem<T>::to_f(src[i]);
+  }
+  __syncthreads();
+  float lsum = 0.f, tsum = 0.f;
+  int ncorr = 0;
+  const int t = threadIdx.x;
+  if (t < npx) {
+    float* row = tile + t * CS;
+    int lab = load_label_rt(y, y_bytes, (int64_t)b * HW + p0 + t);
+    lab = (lab < 0 || lab >= C) ? -1 : lab;
+    float m = row[0];
+    int arg = 0;
+    for (int c = 1; c < C; ++c) {
+      const float zc = row[c];
+      if (zc > m) {
+        m = zc;
+        arg = c;
+      }
+    }
+    const float zy = lab >= 0 ? row[lab] : 0.f;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float e = __expf(row[c] - m);
+      row[c] = e;
+      s += e;
+    }
+    const bool valid = lab >= 0;
+    const bool correct = valid && arg == lab;
+    const float lse = m + __logf(s);
+    const float ce = lse - zy, logp = zy - lse;
+    const float py = __expf(logp), l1p = __logf(1.f + py);
+    const bool need_w = (mode == SEA_MODE_MASK_CE_BAL) || (track_mode == SEA_MODE_MASK_CE_BAL);
+    const float wy = (need_w && valid) ? w[lab] : 1.f;
+    lsum = loss_value(mode, valid, correct, ce, logp, py, l1p, wy);
+    tsum = (track_mode == mode) ? lsum : loss_value(track_mode, valid, correct, ce, logp, py, l1p, wy);
+    ncorr = correct ? 1 : 0;
+    if (pred != nullptr) store_index_rt(pred, pred_bytes, (int64_t)b * HW + p0 + t, arg);
+    if (loss_px != nullptr) loss_px[(int64_t)b * HW + p0 + t] = lsum;
+    if (GRAD) {
+      const float k = grad_coef(mode, valid, correct, logp, py, l1p, wy) * gscale;
+      const float a = k / s;
+      for (int c = 0; c < C; ++c) {
+        const float g = a * row[c];
+        row[c] = (lab == c) ? g - k : g;
+      }
+    }
+  }
+  if (GRAD) {
+    __syncthreads();
+    R* dst = reinterpret_cast<R*>(dlogits) + ((int64_t)b * HW + p0) * C;
+    for (int i = threadIdx.x; i < total; i += 256) {
+      const int p = i / C, c = i - p * C;
+      dst[i] = Elem<T>::from_f(tile[p * CS + c]);
+    }
+  }
+  block_reduce_store(lsum, tsum, ncorr, partials + (int64_t)b * gridDim.x + blockIdx.x);
+}
+
+// ---- second stage: fixed-order sum of the per-block records of each image ------------------------
+__global__ __launch_bounds__(256) void loss_finalize(const BlockPartial* __restrict__ partials, int tiles,
+                                                     float* __restrict__ loss_sum, float* __restrict__ track_sum,
+                                                     int32_t* __restrict__ n_correct) {
+  __shared__ double s_l[256], s_t[256];
+  __shared__ int s_n[256];
+  const int b = blockIdx.x;
+  double l = 0.0, t = 0.0;
+  int n = 0;
+  for (int i = threadIdx.x; i < tiles; i += 256) {
+    const BlockPartial p = partials[(int64_t)b * tiles + i];
+    l += (double)p.loss;
+    t += (double)p.track;
+    n += p.n_correct;
+  }
+  s_l[threadIdx.x] = l;
+  s_t[threadIdx.x] = t;
+  s_n[threadIdx.x] = n;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      s_l[threadIdx.x] += s_l[threadIdx.x + o];
+      s_t[threadIdx.x] += s_t[threadIdx.x + o];
+      s_n[threadIdx.x] += s_n[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    loss_sum[b] = (float)s_l[0];
+    track_sum[b] = (float)s_t[0];
+    n_correct[b] = s_n[0];
+  }
+}
+
+// ---- dispatch --------------------------------------------------------------------------------------
+struct LossArgs {
+  const void* logits;
+  const void* y;
+  int y_bytes;
+  const float* w;
+  int mode, track_mode, B, C;
+  int64_t HW;
+  float gscale;
+  void* dlogits;
+  void* pred;
+  int pred_bytes;
+  float* loss_px;
+  BlockPartial* partials;
+  hipStream_t s;
+  int force_vec;
+};
+
+static inline int tiles_for(int64_t HW, int vec) { return (int)((HW + 256 * vec - 1) / (256 * (int64_t)vec)); }
+// workspace is sized for the smallest tile (VEC=1)
+static inline int max_tiles(int64_t HW) { return tiles_for(HW, 1); }
+
+template <typename T, int CPAD, int VEC>
+static void launch_reg(const LossArgs& a) {
+  dim3 grid(tiles_for(a.HW, VEC), a.B), block(256);
+#define SEA_GO(G, E)                                                                                    \
+  hipLaunchKernelGGL((loss_nchw_reg<T, CPAD, VEC, G, E>), grid, block, 0, a.s, (const T*)a.logits, a.y, \
+                     a.y_bytes, a.w, a.mode, a.track_mode, a.C, a.HW, a.gscale, (T*)a.dlogits, a.pred,  \
+                     a.pred_bytes, a.loss_px, a.partials)
+  const bool exact = (a.C == CPAD);
+  if (a.dlogits) {
+    if (exact)
+      SEA_GO(true, true);
+    else
+      SEA_GO(true, false);
+  } else {
+    if (exact)
+      SEA_GO(false, true);
+    else
+      SEA_GO(false, false);
+  }
+#undef SEA_GO
+}
+
+template <typename T>
+static void launch_stream(const LossArgs& a) {
+  dim3 grid(tiles_for(a.HW, 1), a.B), block(256);
+  if (a.dlogits)
+    hipLaunchKernelGGL((loss_nchw_stream<T, true>), grid, block, 0, a.s, (const T*)a.logits, a.y, a.y_bytes, a.w,
+                       a.mode, a.track_mode, a.C, a.HW, a.gscale, (T*)a.dlogits, a.pred, a.pred_bytes, a.loss_px, a.partials);
+  else
+    hipLaunchKernelGGL((loss_nchw_stream<T, false>), grid, block, 0, a.s, (const T*)a.logits, a.y, a.y_bytes, a.w,
+                       a.mode, a.track_mode, a.C, a.HW, a.gscale, (T*)nullptr, a.pred, a.pred_bytes, a.loss_px, a.partials);
+}
+
+template <typename T>
+static int launch_nhwc(const LossArgs& a) {
+  const int CS = a.C | 1;  // odd row stride (in dwords): lanes hit distinct banks
+  const size_t lds = (size_t)256 * CS * sizeof(float);
+  if (lds > 160 * 1024 - 64) return SEA_ERR_ARG;
+  dim3 grid(tiles_for(a.HW, 1), a.B), block(256);
+  if (a.dlogits) {
+    auto k = loss_nhwc_lds<T, true>;
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, grid, block, lds, a.s, (const T*)a.logits, a.y, a.y_bytes, a.w, a.mode, a.track_mode, a.C,
+                       CS, a.HW, a.gscale, (T*)a.dlogits, a.pred, a.pred_bytes, a.loss_px, a.partials);
+  } else {
+    auto k = loss_nhwc_lds<T, false>;
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, grid, block, lds, a.s, (const T*)a.logits, a.y, a.y_bytes, a.w, a.mode, a.track_mode, a.C,
+                       CS, a.HW, a.gscale, (T*)nullptr, a.pred, a.pred_bytes, a.loss_px, a.partials);
+  }
+  return 0;
+}
+
+// choose the register-resident variant: exact-C instantiations for the datasets of the reference
+// (VOC 21, ADE 151/150, Cityscapes 19), otherwise the smallest CPAD >= C.
+template <typename T>
+static int dispatch_nchw(const LossArgs& a, bool vec4_ok, bool vec2_ok, int* vec_used) {
+  const int C = a.C;
+#define SEA_REG(CP, V)       \
+  do {                       \
+    launch_reg<T, CP, V>(a); \
+    *vec_used = V;           \
+    return 0;                \
+  } while (0)
+  // force_vec: 0 = heuristic, 1/2/4 = benchmark override (falls back when alignment forbids it)
+  const int fv = a.force_vec;
+  if (vec4_ok && (fv == 0 || fv == 4)) {
+    if (C <= 8) SEA_REG(8, 4);
+    if (C <= 16) SEA_REG(16, 4);
+    if (C == 19) SEA_REG(19, 4);
+    if (C == 21) SEA_REG(21, 4);
+    if (C <= 24) SEA_REG(24, 4);
+    if (C <= 32) SEA_REG(32, 4);
+  }
+  if (vec2_ok && (fv == 0 || fv == 2 || fv == 4)) {
+    if (C <= 8) SEA_REG(8, 2);
+    if (C <= 16) SEA_REG(16, 2);
+    if (C == 19) SEA_REG(19, 2);
+    if (C == 21) SEA_REG(21, 2);
+    if (C <= 24) SEA_REG(24, 2);
+    if (C <= 32) SEA_REG(32, 2);
+    if (C <= 48) SEA_REG(48, 2);
+    if (C <= 64) SEA_REG(64, 2);
+  }
+  if (C <= 8) SEA_REG(8, 1);
+  if (C <= 16) SEA_REG(16, 1);
+  if (C == 19) SEA_REG(19, 1);
+  if (C == 21) SEA_REG(21, 1);
+  if (C <= 24) SEA_REG(24, 1);
+  if (C <= 32) SEA_REG(32, 1);
+  if (C <= 48) SEA_REG(48, 1);
+  if (C <= 64) SEA_REG(64, 1);
+  if (C <= 96) SEA_REG(96, 1);
+  if (C <= 128) SEA_REG(128, 1);
+  if (C == 150) SEA_REG(150, 1);
+  if (C == 151) SEA_REG(151, 1);
+  if (C <= 160) SEA_REG(160, 1);
+  if (C <= 192) SEA_REG(192, 1);
+#undef SEA_REG
+  launch_stream<T>(a);
+  *vec_used = 1;
+  return 0;
+}
+
+template <typename T>
+static int dispatch_dtype(const LossArgs& a, int layout, int* tiles_used) {
+  const int y_bytes = a.y_bytes;
+  if (y_bytes != 8 && y_bytes != 4 && y_bytes != 2 && y_bytes != 1) return SEA_ERR_ARG;
+  if (layout == SEA_LAYOUT_NHWC) {
+    *tiles_used = tiles_for(a.HW, 1);
+    return launch_nhwc<T>(a);
+  }
+  if (layout != SEA_LAYOUT_NCHW) return SEA_ERR_ARG;
+  // vector width: every plane start (b*C+c)*HW + px0 must be VEC-element aligned
+  auto al = [&](int vec) {
+    const uintptr_t bytes = sizeof(T) * vec;
+    return (a.HW % vec) == 0 && (((uintptr_t)a.logits) % bytes) == 0 &&
+           (!a.dlogits || (((uintptr_t)a.dlogits) % bytes) == 0);
+  };
+  int vec = 1;
+  const int rc = dispatch_nchw<T>(a, al(4), al(2), &vec);
+  *tiles_used = tiles_for(a.HW, vec);
+  return rc;
+}
+
+static int loss_fwd_bwd_impl(const void* logits, int dtype, int layout, const void* y, int y_bytes, const float* w,
+                             int mode, int track_mode, int B, int C, int64_t HW, float grad_scale, void* dlogits,
+                             void* pred, int pred_bytes, float* loss_px, void* workspace, size_t workspace_bytes,
+                             float* loss_sum, float* track_sum, int32_t* n_correct, void* stream, int force_vec) {
+  SEA_CHECK_ARG(logits && y && workspace && loss_sum && track_sum && n_correct);
+  SEA_CHECK_ARG(B > 0 && B <= 65535 && C > 0 && HW > 0);
+  SEA_CHECK_ARG(mode >= 0 && mode <= 3 && track_mode >= 0 && track_mode <= 3);
+  SEA_CHECK_ARG(!((mode == SEA_MODE_MASK_CE_BAL || track_mode == SEA_MODE_MASK_CE_BAL) && w == nullptr));
+  SEA_CHECK_ARG(pred == nullptr || pred_bytes == 8 || pred_bytes == 4 || pred_bytes == 2 || pred_bytes == 1);
+  SEA_CHECK_ARG(!(pred && pred_bytes == 1 && C > 255) && !(pred && pred_bytes == 2 && C > 32767));
+  SEA_CHECK_ARG(!(y_bytes == 1 && C > 255));
+  SEA_CHECK_ARG(workspace_bytes >= sea_loss_workspace_bytes(B, HW));
+  SEA_CHECK_ARG((((uintptr_t)workspace) & 15) == 0);
+  LossArgs a{logits, y, y_bytes, w, mode, track_mode, B, C, HW, grad_scale, dlogits, pred, pred_bytes,
+             loss_px, (BlockPartial*)workspace, (hipStream_t)stream, force_vec};
+  int tiles = 0, rc;
+  switch (dtype) {
+    case SEA_DTYPE_F32: rc = dispatch_dtype<float>(a, layout, &tiles); break;
+    case SEA_DTYPE_BF16: rc = dispatch_dtype<__hip_bfloat16>(a, layout, &tiles); break;
+    case SEA_DTYPE_F16: rc = dispatch_dtype<__half>(a, layout, &tiles); break;
+    default: return SEA_ERR_ARG;
+  }
+  if (rc) return rc;
+  hipLaunchKernelGGL(loss_finalize, dim3(B), dim3(256), 0, a.s, (const BlockPartial*)workspace, tiles, loss_sum,
+                     track_sum, n_correct);
+  SEA_RETURN_LAST();
+}
+
+}  // namespace sea
+
+using namespace sea;
+
+extern "C" size_t sea_loss_workspace_bytes(int B, int64_t HW) {
+  if (B <= 0 || HW <= 0) return 0;
+  return (size_t)B * (size_t)max_tiles(HW) * sizeof(BlockPartial);
+}
+
+extern "C" int sea_loss_fwd_bwd(const void* logits, int dtype, int layout, const void* y, int y_bytes,
+                                const float* w, int mode, int track_mode, int B, int C, int64_t HW,
+                                float grad_scale, void* dlogits, void* pred, int pred_bytes, float* loss_px,
+                                void* workspace, size_t workspace_bytes, float* loss_sum, float* track_sum, int32_t* n_correct,
+                                void* stream) {
+  return loss_fwd_bwd_impl(logits, dtype, layout, y, y_bytes, w, mode, track_mode, B, C, HW, grad_scale, dlogits,
+                           pred, pred_bytes, loss_px, workspace, workspace_bytes, loss_sum, track_sum, n_correct, stream, 0);
+}
+
+// benchmark hook: same as sea_loss_fwd_bwd but pins the pixels-per-lane of the register kernel
+extern "C" int sea_loss_fwd_bwd_tuned(const void* logits, int dtype, int layout, const void* y, int y_bytes,
+                                      const float* w, int mode, int track_mode, int B, int C, int64_t HW,
+                                      float grad_scale, void* dlogits, void* pred, int pred_bytes, float* loss_px,
+                                      void* workspace, size_t workspace_bytes, float* loss_sum, float* track_sum,
+                                      int32_t* n_correct, void* stream, int force_vec) {
+  return loss_fwd_bwd_impl(logits, dtype, layout, y, y_bytes, w, mode, track_mode, B, C, HW, grad_scale, dlogits,
+                           pred, pred_bytes, loss_px, workspace, workspace_bytes, loss_sum, track_sum, n_correct, stream,
+                           force_vec);
+}

@@ -1,0 +1,256 @@
+"""ctypes binding of libsea_hip.so (include/sea_hip.h) + thin torch-tensor wrappers.
+
+PyTorch is plumbing here: it owns device memory and the stream; every kernel is launched through
+the C ABI with raw pointers.  There is NO fallback: if the library is missing or a tensor is not on a
+HIP device the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch  # must be imported before the library so that ITS libamdhip64 (same SONAME) is the one bound
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.environ.get("SEA_HIP_LIB", os.path.join(_PKG, "lib", "libsea_hip.so"))
+
+MODE_BY_NAME = {"mask-ce-avg": 0, "mask-ce-bal": 1, "js-avg": 2, "ce": 3, "ce-avg": 3}
+DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
+
+_lib = None
+
+_vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+_SIGS = {
+    "sea_abi_version": (C.c_int, []),
+    "sea_build_info": (C.c_char_p, []),
+    "sea_apgd_linf_step": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _i, _i64, _vp]),
+    "sea_linf_random_start": (_i, [_vp, _vp, _f, _vp, _i64, _vp]),
+    "sea_linf_project": (_i, [_vp, _vp, _f, _vp, _i64, _vp]),
+    "sea_pgd_linf_step": (_i, [_vp, _vp, _vp, _f, _f, _vp, _vp, _i, _i64, _vp]),
+    "sea_loss_workspace_bytes": (_sz, [_i, _i64]),
+    "sea_loss_fwd_bwd": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i64, _f, _vp, _vp, _i, _vp, _vp, _sz,
+                              _vp, _vp, _vp, _vp]),
+    "sea_loss_fwd_bwd_tuned": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i64, _f, _vp, _vp, _i, _vp, _vp,
+                                    _sz, _vp, _vp, _vp, _vp, _i]),
+    "sea_class_counts": (_i, [_vp, _i, _vp, _i, _i, _i, _i64, _i, _i, _vp, _vp, _vp, _vp]),
+    "sea_confusion": (_i, [_vp, _i, _vp, _i, _i64, _i, _vp, _vp]),
+    "sea_apgd_track": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                            _vp, _vp, _vp]),
+    "sea_select_copy": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _vp]),
+    "sea_count_ignored": (_i, [_vp, _i, _i, _i64, _vp, _vp]),
+    "sea_worst_miou_greedy": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
+}
+EXPORTS = tuple(_SIGS)
+
+
+class SeaNativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises SeaNativeError if the library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SeaNativeError(
+                f"libsea_hip.so not found at {LIB_PATH}: build it with "
+                "`python robust-segmentation_amd/build_native.py` (there is no CPU fallback)")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(h, name)  # AttributeError here = ABI mismatch
+            fn.restype, fn.argtypes = res, args
+        _lib = h
+    return _lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise SeaNativeError(f"{what} failed with hipError {rc}")
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise SeaNativeError("libsea_hip works on HIP device tensors only (no CPU fallback); got a CPU tensor")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise SeaNativeError("expected a contiguous float32 tensor")
+    return t
+
+
+_INT_BYTES = {torch.int64: 8, torch.int32: 4, torch.int16: 2, torch.uint8: 1}
+
+
+def int_bytes(t: torch.Tensor) -> int:
+    try:
+        return _INT_BYTES[t.dtype]
+    except KeyError:
+        raise SeaNativeError(f"unsupported label/index dtype {t.dtype}") from None
+
+
+# ------------------------------------------------------------------------------------------------ K1/K5/K6
+def apgd_linf_step(x, x_adv, x_old, grad, step_b, eps: float, a: float, out=None):
+    _dev(x, x_adv, x_old, grad, step_b)
+    B = x.shape[0]
+    out = torch.empty_like(x) if out is None else out
+    _check(lib().sea_apgd_linf_step(_p(_f32c(x)), _p(_f32c(x_adv)), _p(_f32c(x_old)), _p(_f32c(grad)),
+                                    _p(_f32c(step_b)), eps, a, _p(_f32c(out)), B, x[0].numel(), _stream()),
+           "sea_apgd_linf_step")
+    return out
+
+
+def linf_random_start(x, u, eps: float, out=None):
+    _dev(x, u)
+    out = torch.empty_like(x) if out is None else out
+    _check(lib().sea_linf_random_start(_p(_f32c(x)), _p(_f32c(u)), eps, _p(_f32c(out)), x.numel(), _stream()),
+           "sea_linf_random_start")
+    return out
+
+
+def linf_project(z, x, eps: float, out=None):
+    _dev(z, x)
+    out = torch.empty_like(x) if out is None else out
+    _check(lib().sea_linf_project(_p(_f32c(z)), _p(_f32c(x)), eps, _p(_f32c(out)), x.numel(), _stream()),
+           "sea_linf_project")
+    return out
+
+
+def pgd_linf_step(X, delta, grad, alpha: float, eps: float, delta_out=None, x_in_out=None, clamp_input=False):
+    _dev(X, delta, grad)
+    delta_out = torch.empty_like(delta) if delta_out is None else delta_out
+    _check(lib().sea_pgd_linf_step(_p(_f32c(X)), _p(_f32c(delta)), _p(_f32c(grad)), alpha, eps, _p(_f32c(delta_out)),
+                                   _p(x_in_out), int(clamp_input), X.numel(), _stream()), "sea_pgd_linf_step")
+    return delta_out
+
+
+# ------------------------------------------------------------------------------------------------ K2
+def logits_layout(logits: torch.Tensor):
+    """(tensor usable by the kernel, layout code).  NCHW-contiguous and channels_last are both native."""
+    if logits.dim() != 4:
+        raise SeaNativeError("logits must be (B,C,H,W)")
+    if logits.is_contiguous():
+        return logits, LAYOUT_NCHW
+    if logits.is_contiguous(memory_format=torch.channels_last):
+        return logits, LAYOUT_NHWC
+    return logits.contiguous(), LAYOUT_NCHW
+
+
+def loss_workspace(B: int, HW: int, device) -> torch.Tensor:
+    n = lib().sea_loss_workspace_bytes(B, HW)
+    return torch.empty(n, dtype=torch.uint8, device=device)
+
+
+def loss_fwd_bwd(logits, y, weights, mode: int, track_mode: int, grad_scale: float, want_grad: bool = True,
+                 pred=None, loss_px=None, workspace=None, out=None, dlogits=None, force_vec: int = 0):
+    """Run K2.  Returns dict(dlogits, loss_sum, track_sum, n_correct, pred)."""
+    _dev(logits, y, weights, pred, loss_px)
+    logits, layout = logits_layout(logits)
+    B, Cc, H, W = logits.shape
+    HW = H * W
+    if y.shape != (B, H, W) or not y.is_contiguous():
+        raise SeaNativeError("labels must be a contiguous (B,H,W) tensor")
+    dev = logits.device
+    if workspace is None:
+        workspace = loss_workspace(B, HW, dev)
+    if out is None:
+        out = (torch.empty(B, dtype=torch.float32, device=dev), torch.empty(B, dtype=torch.float32, device=dev),
+               torch.empty(B, dtype=torch.int32, device=dev))
+    if want_grad and dlogits is None:
+        dlogits = torch.empty_like(logits)  # preserves the memory format
+    if not want_grad:
+        dlogits = None
+    if weights is not None:
+        weights = _f32c(weights)
+        if weights.numel() != Cc:
+            raise SeaNativeError("class weights must have C entries")
+    L = lib()
+    args = [_p(logits), DTYPE_CODE[logits.dtype], layout, _p(y), int_bytes(y), _p(weights), mode, track_mode, B, Cc,
+            HW, grad_scale, _p(dlogits), _p(pred), 0 if pred is None else int_bytes(pred), _p(loss_px),
+            _p(workspace), workspace.numel(), _p(out[0]), _p(out[1]), _p(out[2]), _stream()]
+    if force_vec:
+        _check(L.sea_loss_fwd_bwd_tuned(*args, force_vec), "sea_loss_fwd_bwd_tuned")
+    else:
+        _check(L.sea_loss_fwd_bwd(*args), "sea_loss_fwd_bwd")
+    return dict(dlogits=dlogits, loss_sum=out[0], track_sum=out[1], n_correct=out[2], pred=pred)
+
+
+# ------------------------------------------------------------------------------------------------ K3
+def class_counts(pred, y, n_cls: int, per_image: bool = False, mask_pred: bool = True, out=None):
+    """(inter, pred_cnt, tgt_cnt) int64; accumulates into `out` when given."""
+    _dev(pred, y)
+    B = pred.shape[0]
+    HW = pred[0].numel()
+    shape = (B, n_cls) if per_image else (n_cls,)
+    if out is None:
+        out = tuple(torch.zeros(shape, dtype=torch.int64, device=pred.device) for _ in range(3))
+    if not (pred.is_contiguous() and y.is_contiguous()):
+        raise SeaNativeError("pred / labels must be contiguous")
+    _check(lib().sea_class_counts(_p(pred), int_bytes(pred), _p(y), int_bytes(y), B, n_cls, HW, int(mask_pred),
+                                  int(per_image), _p(out[0]), _p(out[1]), _p(out[2]), _stream()), "sea_class_counts")
+    return out
+
+
+def confusion(pred, y, n_cls: int, hist=None):
+    _dev(pred, y)
+    if hist is None:
+        hist = torch.zeros(n_cls, n_cls, dtype=torch.int64, device=pred.device)
+    _check(lib().sea_confusion(_p(pred.contiguous()), int_bytes(pred), _p(y.contiguous()), int_bytes(y), pred.numel(),
+                               n_cls, _p(hist), _stream()), "sea_confusion")
+    return hist
+
+
+def count_ignored(y, out=None):
+    _dev(y)
+    B = y.shape[0]
+    out = torch.empty(B, dtype=torch.int32, device=y.device) if out is None else out
+    _check(lib().sea_count_ignored(_p(y), int_bytes(y), B, y[0].numel(), _p(out), _stream()), "sea_count_ignored")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ K4/K7
+def apgd_track(stats, n_ignored, HW: int, it: int, n_iter: int, check_k: int, early_stop: bool, init: bool, st):
+    """`st` is the ApgdState of semseg.attacker (device buffers)."""
+    _check(lib().sea_apgd_track(_p(stats["loss_sum"]), _p(stats["track_sum"]), _p(stats["n_correct"]),
+                                _p(n_ignored), st.B, HW, it, n_iter, check_k, int(early_stop), int(init),
+                                _p(st.acc_cnt), _p(st.acc), _p(st.loss_best), _p(st.loss_best_last),
+                                _p(st.reduced_last), _p(st.step), _p(st.loss_steps), _p(st.flags), _p(st.done),
+                                _stream()), "sea_apgd_track")
+
+
+def select_copy(flags, x_adv, grad, x_best, grad_best, x_best_adv, pred=None, pred_best=None):
+    B = x_adv.shape[0]
+    _check(lib().sea_select_copy(_p(flags), _p(_f32c(x_adv)), _p(_f32c(grad)), _p(_f32c(x_best)),
+                                 _p(_f32c(grad_best)), _p(_f32c(x_best_adv)), _p(pred), _p(pred_best),
+                                 0 if pred is None else int_bytes(pred), B, x_adv[0].numel(),
+                                 0 if pred is None else pred[0].numel(), _stream()), "sea_select_copy")
+
+
+# ------------------------------------------------------------------------------------------------ K9 (host)
+def worst_miou_greedy(ints: torch.Tensor, unions: torch.Tensor, mt_state, n_rounds: int = 1000):
+    """ints/unions: CPU float32 (A,N,C).  mt_state: 625 ints (random.getstate()[1]).
+    Returns (miou, selected list, rounds, new mt_state tuple)."""
+    import numpy as np
+    A, N, Cc = ints.shape
+    ti = np.ascontiguousarray(ints.detach().cpu().numpy(), dtype=np.float32)
+    tu = np.ascontiguousarray(unions.detach().cpu().numpy(), dtype=np.float32)
+    mt = np.array(mt_state, dtype=np.uint32)
+    assert mt.shape == (625,)
+    sel = np.zeros(N, dtype=np.int32)
+    miou = C.c_double(0.0)
+    rounds = C.c_int32(0)
+    rc = lib().sea_worst_miou_greedy(ti.ctypes.data, tu.ctypes.data, A, N, Cc, mt.ctypes.data, n_rounds,
+                                     C.addressof(miou), sel.ctypes.data, C.addressof(rounds))
+    _check(rc, "sea_worst_miou_greedy")
+    return miou.value, sel.tolist(), rounds.value, tuple(int(v) for v in mt)

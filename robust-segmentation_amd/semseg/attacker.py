@@ -1,0 +1,434 @@
+"""SEA attack engine: APGD (L-inf) with the SEA losses, device-resident on MI355X.
+
+Call-compatible with the reference module of the same name (semseg/attacker.py): same function
+names, positional order, defaults and return tuples, so ``tools/infer.py`` style callers such as
+
+    attack_fn = partial(attacker.apgd_largereps, norm="Linf", eps=eps/255, n_iter=300, use_rs=True,
+                        loss="mask-ce-bal", track_loss="ce-avg", early_stop=True, num_classes=C)
+    x_adv, _, acc = attack_fn(model, x.clone(), y, weights)
+
+work unchanged.  What differs is HOW an iteration runs:
+
+* the ~14 element-wise launches of the step (reference lines 389-410) are one kernel (K1);
+* loss forward, its logit gradient, the tracking loss, per-image accuracy and the argmax are one
+  kernel over the (B,C,H,W) logits (K2, closed-form gradients, JS in closed form);
+* every per-image decision (best-adv, best-loss, oscillation check, step halving, early stop) is
+  taken by a one-block kernel on the device (K4/K7) and applied by one conditional-copy kernel:
+  the loop never calls ``.nonzero()``, ``.cpu()`` or ``.sum() > 0`` and never launches the
+  2*n_cls-iteration ``compute_iou_acc`` unless ``verbose``.
+
+Only device tensors are accepted: there is no CPU fallback (see semseg/_native.py).
+"""
+from __future__ import annotations
+
+import math
+from functools import partial
+from typing import Optional
+
+import torch
+
+from . import _native as N
+
+__all__ = [
+    "apgd_train", "apgd_largereps", "apgd_restarts", "criterion_dict", "masked_cross_entropy",
+    "masked_cross_entropy_balanced", "js_loss", "js_div_fn", "pixel_to_img_loss", "compute_iou_acc",
+    "check_oscillation", "Logger",
+]
+
+
+class Logger:
+    """print + append to file (the autoattack.other_utils.Logger the reference imports, attacker.py:6)."""
+
+    def __init__(self, log_path=None):
+        self.log_path = log_path
+
+    def log(self, str_to_log):
+        print(str_to_log)
+        if self.log_path is not None:
+            with open(self.log_path, "a") as f:
+                f.write(str_to_log + "\n")
+                f.flush()
+
+
+# ---------------------------------------------------------------------------------------------------
+# differentiable per-pixel losses (API surface of reference lines 143-257)
+# ---------------------------------------------------------------------------------------------------
+class _PixelLoss(torch.autograd.Function):
+    """loss map (B,H,W) of one SEA loss; backward = closed-form d loss/d logits times the upstream
+    per-pixel gradient (the mask of the masked losses is detached in the reference, line 148)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, weights, mode):
+        B, Cc, H, W = logits.shape
+        lg = logits.detach()
+        loss_px = torch.empty(B, H, W, dtype=torch.float32, device=logits.device)
+        need_grad = logits.requires_grad
+        r = N.loss_fwd_bwd(lg, target.contiguous(), weights, mode, mode, 1.0, want_grad=need_grad, loss_px=loss_px)
+        ctx.save_for_backward(r["dlogits"]) if need_grad else None
+        ctx.has_grad = need_grad
+        return loss_px
+
+    @staticmethod
+    def backward(ctx, g):
+        if not ctx.has_grad:
+            return None, None, None, None
+        (dl,) = ctx.saved_tensors
+        return dl * g.unsqueeze(1).to(dl.dtype), None, None, None
+
+
+def _loss_map(pred, target, weights, mode):
+    if weights is not None:
+        weights = weights.to(device=pred.device, dtype=torch.float32)
+    return _PixelLoss.apply(pred, target, weights, mode)
+
+
+def masked_cross_entropy(pred, target, weights=None, reduction="none", ignore_index=-1):
+    """Cross-entropy of only correctly classified pixels (reference lines 143-152)."""
+    loss = _loss_map(pred, target, None, 0)
+    if reduction == "mean":
+        return loss.view(pred.shape[0], -1).mean(-1)
+    return loss
+
+
+def masked_cross_entropy_balanced(pred, target, weights=None, reduction="none", ignore_index=-1):
+    """Class-balanced cross-entropy of only correctly classified pixels (reference lines 155-173)."""
+    loss = _loss_map(pred, target, weights, 1)
+    if reduction == "mean":
+        return loss.view(pred.shape[0], -1).mean(-1)
+    return loss
+
+
+def js_div_fn(p, q, weights=None, softmax_output=False, reduction="none", red_dim=None, ignore_index=-1):
+    """JS divergence between softmax(p) and one-hot(q) (reference lines 187-226).  The fused kernel
+    yields the class-summed value, so ``red_dim`` must sum over the class dim (what js_loss does)."""
+    if softmax_output or reduction != "none" or red_dim not in (1, (1,), [1]):
+        raise NotImplementedError("only the js_loss configuration (logits in, red_dim=1) is implemented in HIP")
+    return _loss_map(p, q, None, 2)
+
+
+def js_loss(p, q, num_classes=21, reduction="mean"):
+    loss = js_div_fn(p, q, red_dim=(1))
+    if reduction == "mean":
+        return loss.view(p.shape[0], -1).mean(-1)
+    elif reduction == "none":
+        return loss
+
+
+def _ce(x, y, *unused):
+    # the reference's 2-argument lambdas (lines 252-253) make `loss="ce"` a TypeError inside apgd_train
+    # (SURVEY fact 3 / D3); accepting the ignored third argument keeps those call sites alive.
+    return _loss_map(x, y, None, 3)
+
+
+def pixel_to_img_loss(loss, mask_background=None):
+    if mask_background is not None:
+        loss = mask_background * loss
+    return loss.view(loss.shape[0], -1).mean(-1)
+
+
+criterion_dict = {
+    "ce": _ce,
+    "ce-avg": _ce,
+    "mask-ce-avg": masked_cross_entropy,
+    "mask-ce-bal": masked_cross_entropy_balanced,
+    "js-avg": partial(js_loss, reduction="none"),
+}
+
+
+# ---------------------------------------------------------------------------------------------------
+# statistics helpers
+# ---------------------------------------------------------------------------------------------------
+def compute_iou_acc(pred, target, n_cls, verbose=False, ignore_index=-1, device=None):
+    """(m_acc, a_acc, m_iou) as 0-dim CPU float32 tensors (reference lines 9-52): one histogram kernel
+    instead of 2*n_cls Python iterations.  Like the reference it overwrites ``pred`` with the ignore
+    label at ignored pixels in place (line 20)."""
+    pred[target == ignore_index] = ignore_index
+    inter, pc, tc = N.class_counts(pred.contiguous(), target.contiguous(), n_cls, per_image=False, mask_pred=False)
+    inter, pc, tc = inter.float(), pc.float(), tc.float()
+    union = tc + pc - inter
+    ind = tc > 0
+    m_acc = (inter[ind] / tc[ind]).mean().cpu()
+    a_acc = (inter.sum() / tc.sum()).cpu()
+    ind = union > 0
+    m_iou = (inter[ind] / union[ind]).mean().cpu()
+    if verbose:
+        print(f"mAcc={m_acc:.2%} aAcc={a_acc:.2%}", f" mIoU={m_iou:.2%}")
+    return m_acc, a_acc, m_iou
+
+
+def check_oscillation(x, j, k, y5, k3=0.75):
+    """Reference lines 243-248 (kept for API parity; the attack itself does this inside K7)."""
+    t = torch.zeros(x.shape[1], device=x.device)
+    for counter5 in range(k):
+        t += (x[j - counter5] > x[j - counter5 - 1]).float()
+    return (t <= k * k3 * torch.ones_like(t)).float()
+
+
+def apgd_checkpoints(n_iter: int):
+    """{iteration: window k} of the step-size checks; data independent (reference lines 323-329, 528-551)."""
+    k = max(int(0.22 * n_iter), 1)
+    k_min = max(int(0.06 * n_iter), 1)
+    dec = max(int(0.03 * n_iter), 1)
+    out, c3 = {}, 0
+    for i in range(n_iter):
+        c3 += 1
+        if c3 == k:
+            out[i] = k
+            c3 = 0
+            k = max(k - dec, k_min)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# device-resident state
+# ---------------------------------------------------------------------------------------------------
+class ApgdState:
+    """All per-image bookkeeping of one apgd_train call, resident in HBM."""
+
+    def __init__(self, B: int, n_iter: int, eps: float, device):
+        f32 = dict(dtype=torch.float32, device=device)
+        self.B = B
+        self.acc_cnt = torch.zeros(B, dtype=torch.int32, device=device)
+        self.acc = torch.zeros(B, **f32)
+        self.loss_best = torch.zeros(B, **f32)
+        self.loss_best_last = torch.zeros(B, **f32)
+        self.reduced_last = torch.ones(B, **f32)
+        self.step = torch.full((B,), 2.0 * eps, **f32)  # alpha * eps, alpha = 2 (reference lines 329, 339)
+        self.loss_steps = torch.zeros(max(n_iter, 1), B, **f32)
+        self.flags = torch.zeros(3, B, dtype=torch.uint8, device=device)
+        self.done = torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def compact_labels(y: torch.Tensor, n_cls: int) -> torch.Tensor:
+    """int64 labels -> uint8 (255 = ignore) or int16: the labels are read every iteration but never change,
+    so the 8-byte reads of the reference become 1-2 bytes per pixel."""
+    if y.dtype in (torch.uint8, torch.int16):
+        return y.contiguous()
+    if n_cls <= 255:
+        return torch.where(y < 0, torch.full_like(y, 255), y).to(torch.uint8).contiguous()
+    return y.to(torch.int16).contiguous()
+
+
+def _forward_logits(model, x_buf, want_grad: bool):
+    x_in = x_buf.detach()
+    if want_grad:
+        x_in.requires_grad_(True)
+        with torch.enable_grad():
+            logits = model(x_in)
+    else:
+        with torch.no_grad():
+            logits = model(x_in)
+    return x_in, logits
+
+
+def _input_grad(logits, x_in, dlogits):
+    (g,) = torch.autograd.grad(logits, [x_in], grad_outputs=dlogits)
+    return g if g.is_contiguous() else g.contiguous()
+
+
+class ApgdRun:
+    """One APGD run as an object: ``start()`` is step 0 (reference lines 342-383), ``step(i)`` is loop
+    iteration i (lines 385-569).  ``apgd_train`` drives it; bench.py times ``step`` directly.
+    Nothing in ``step`` synchronises with the host."""
+
+    def __init__(self, model, x, y, eps, n_iter, loss, track_loss, early_stop, num_classes, weights, x_start):
+        self.model = model
+        self.mode = N.MODE_BY_NAME[loss]
+        self.tmode = N.MODE_BY_NAME[track_loss] if track_loss is not None else self.mode
+        self.eps, self.n_iter, self.early_stop, self.num_classes = float(eps), n_iter, early_stop, num_classes
+        self.x = x
+        self.y = y
+        device = x.device
+        B = x.shape[0]
+        self.B, self.HW = B, x.shape[-2] * x.shape[-1]
+        self.x_adv = x_start
+        self.yc = compact_labels(y, num_classes)
+        self.n_ignored = N.count_ignored(self.yc)
+        self.w = None
+        if weights is not None and (self.mode == 1 or self.tmode == 1):
+            self.w = weights.to(device=device, dtype=torch.float32).contiguous()
+        self.st = ApgdState(B, n_iter, self.eps, device)
+        self.cps = apgd_checkpoints(n_iter)
+        pred_dtype = torch.uint8 if num_classes <= 255 else torch.int16
+        self.pred = torch.empty(B, x.shape[-2], x.shape[-1], dtype=pred_dtype, device=device)
+        self.stats = (torch.empty(B, dtype=torch.float32, device=device),
+                      torch.empty(B, dtype=torch.float32, device=device),
+                      torch.empty(B, dtype=torch.int32, device=device))
+        self.ws = N.loss_workspace(B, self.HW, device)
+        self.gscale = 1.0 / float(self.HW)
+        self.dlogits = None
+        self.last = None       # K2 outputs of the latest iterate
+        self.k2_events = None  # optional list of (start, end) event pairs, one per step (bench.py)
+
+    def _loss(self, logits, want_grad):
+        ev = None
+        if self.k2_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        r = N.loss_fwd_bwd(logits.detach(), self.yc, self.w, self.mode, self.tmode, self.gscale, want_grad=want_grad,
+                           pred=self.pred, workspace=self.ws, out=self.stats,
+                           dlogits=self.dlogits if want_grad else None)
+        if ev is not None:
+            ev[1].record()
+            self.k2_events.append(ev)
+        if want_grad:
+            self.dlogits = r["dlogits"]
+        self.last = r
+        return r
+
+    def start(self):
+        x_in, logits = _forward_logits(self.model, self.x_adv, True)
+        r = self._loss(logits, True)
+        self.grad = _input_grad(logits, x_in, r["dlogits"])
+        del logits
+        N.apgd_track(r, self.n_ignored, self.HW, 0, max(self.n_iter, 1), 0, False, True, self.st)
+        self.pred_best = self.pred.clone()
+        self.x_best = self.x_adv.clone()
+        self.x_best_adv = self.x_adv.clone()
+        self.grad_best = self.grad.clone()
+        self.x_old = self.x_adv.clone()
+        self.x_next = torch.empty_like(self.x_adv)
+
+    def step(self, i: int):
+        # ---- gradient step (reference lines 389-456): K1, then rotate the three iterate buffers
+        a = 0.75 if i > 0 else 1.0
+        N.apgd_linf_step(self.x, self.x_adv, self.x_old, self.grad, self.st.step, self.eps, a, out=self.x_next)
+        self.x_old, self.x_adv, self.x_next = self.x_adv, self.x_next, self.x_old
+        # ---- model forward, fused loss/grad/track/acc/argmax (K2), model input-gradient
+        want = i < self.n_iter - 1  # the reference skips the last backward (line 467)
+        x_in, logits = _forward_logits(self.model, self.x_adv, want)
+        r = self._loss(logits, want)
+        if want:
+            self.grad = _input_grad(logits, x_in, r["dlogits"])
+        del logits
+        # ---- bookkeeping on the device (K7 decisions, K4 copies)
+        N.apgd_track(r, self.n_ignored, self.HW, i, self.n_iter, self.cps.get(i, 0), self.early_stop, False, self.st)
+        N.select_copy(self.st.flags, self.x_adv, self.grad, self.x_best, self.grad_best, self.x_best_adv, self.pred,
+                      self.pred_best)
+
+    def result(self):
+        return self.x_best, self.st.acc, self.st.loss_best, self.x_best_adv
+
+
+def apgd_train(model, x, y, norm, eps, n_iter=10, use_rs=False, loss="ce", verbose=False, is_train=False,
+               early_stop=False, track_loss=None, logger=None, y_target=None, ignore_index=-1, x_init=None,
+               num_classes=21, weights=None, gpuu=None, noise=None, poll_every: int = 8):
+    """One APGD run (reference lines 260-571).  Returns ``(x_best, acc, loss_best, x_best_adv)``.
+
+    Extra keyword arguments (all optional): ``gpuu`` is accepted and ignored (tools/train_rob_seg.py
+    passes it); ``noise`` replaces ``torch.rand_like(x)`` of the random start so CPU and
+    device runs can share it; ``poll_every`` = how often the host looks at the early-stop flag.
+    """
+    assert not model.training
+    assert ignore_index == -1, "Only `ignore_index = 1` is supported."
+    if norm != "Linf":
+        raise NotImplementedError("only the L-inf attack of SEA / PIR-AT is implemented (SURVEY fact 2)")
+    if loss not in N.MODE_BY_NAME:
+        raise KeyError(loss)
+    if not x.is_cuda:
+        raise N.SeaNativeError("apgd_train needs HIP device tensors (no CPU fallback)")
+    device = x.device
+    x = x.detach().contiguous().float()
+
+    # ---- start point (reference lines 288-308); the RNG is consumed even when x_init overrides it
+    if not use_rs:
+        x_adv = x.clone()
+    else:
+        t = torch.rand_like(x) if noise is None else noise.to(device)
+        x_adv = N.linf_random_start(x, t.contiguous(), float(eps))
+    if x_init is not None:
+        x_adv = x_init.detach().clone().contiguous().float()
+    x_adv = x_adv.clamp_(0.0, 1.0)
+
+    run = ApgdRun(model, x, y, eps, n_iter, loss, track_loss, early_stop, num_classes, weights, x_adv)
+    if logger is not None and verbose:
+        n_ign = int(run.n_ignored.sum())
+        if n_ign > 0:
+            logger.log(f"{n_ign / y.numel():.2%} pixels are masked out.")
+    run.start()
+    if verbose:
+        m_acc, a_acc, m_iou = compute_iou_acc(run.pred_best.long(), y, num_classes)
+
+    done_host = torch.zeros(1, dtype=torch.int32).pin_memory() if early_stop else None
+    done_evt = None
+    for i in range(n_iter):
+        run.step(i)
+        if verbose:
+            st, r = run.st, run.last
+            m_acc, a_acc, m_iou = compute_iou_acc(run.pred_best.long(), y, num_classes)
+            if logger is not None:
+                logger.log("iteration: {} - best loss: {:.6f} curr loss {:.6f} - mAcc={:.2%} aAcc={:.2%} "
+                           "mIoU={:.2%} - step size: {:.5f}".format(
+                               i, st.loss_best.sum().item(), (r["track_sum"].sum() / run.HW).item() / run.B, m_acc,
+                               a_acc, m_iou, st.step.mean().item()))
+        # ---- early stop (reference lines 568-569): the flag lives on the device and freezes all state
+        # from the next iteration on, so looking at it late never changes the result.
+        if early_stop:
+            if done_evt is not None and done_evt.query():
+                if int(done_host[0]) != 0:
+                    break
+                done_evt = None
+            if done_evt is None and (i % poll_every) == poll_every - 1:
+                done_host.copy_(run.st.done, non_blocking=True)
+                done_evt = torch.cuda.Event()
+                done_evt.record()
+    return run.result()
+
+
+def apgd_restarts(model, x, y, norm="Linf", eps=8.0 / 255.0, n_iter=10, loss="ce", verbose=False, n_restarts=1,
+                  log_path=None, early_stop=False, eot_iter=0, track_loss=None, use_rs=False, ignore_index=-1):
+    """APGD with restarts on the still-robust images (reference lines 574-659).  Not used by SEA
+    (tools/infer.py uses apgd_largereps); kept for API parity.  Targeted losses are not implemented."""
+    if "targeted" in loss:
+        raise NotImplementedError("targeted losses are outside the SEA hot path")
+    logger = Logger(log_path)
+    acc = torch.ones([x.shape[0]], device=x.device)
+    x_adv = x.clone()
+    for i in range(n_restarts):
+        ind = acc > 0
+        if acc.sum() > 0:
+            _, _, _, x_adv_curr = apgd_train(model, x[ind], y[ind], n_iter=n_iter, use_rs=use_rs, verbose=verbose,
+                                             loss=loss, eps=eps, norm=norm, logger=logger, early_stop=early_stop,
+                                             track_loss=track_loss, ignore_index=ignore_index)
+            with torch.no_grad():
+                pred = model(x_adv_curr).max(1)[1] == y[ind]
+            pred[y[ind] == ignore_index] = True
+            acc_curr = pred.float().view(x_adv_curr.shape[0], -1).mean(-1)
+            to_update = acc_curr < acc[ind]
+            succs = torch.nonzero(ind).squeeze()
+            if len(succs.shape) == 0:
+                succs.unsqueeze_(0)
+            x_adv[succs[to_update]] = x_adv_curr[to_update].clone()
+            acc[succs[to_update]] = acc_curr[to_update].clone()
+            logger.log(f"restart {i + 1} robust accuracy={acc.float().mean():.1%}")
+    return x_adv, None, acc
+
+
+def largereps_schedule(n_iter: int, eps: float):
+    """Stage lengths [int(.3n), int(.3n), rest] and radii [2eps, 1.5eps, eps] (reference lines 693-695)."""
+    n_iters = [int(c * n_iter) for c in [0.3, 0.3]]
+    n_iters.append(n_iter - sum(n_iters))
+    return n_iters, [c * eps for c in [2, 1.5, 1]]
+
+
+def apgd_largereps(model, x, y, weights, norm="Linf", eps=8.0 / 255.0, n_iter=10, loss="ce", verbose=False,
+                   n_restarts=1, log_path=None, early_stop=False, eot_iter=0, track_loss=None, use_rs=False,
+                   ignore_index=-1, num_classes=21, noises=None):
+    """The SEA attack schedule: three APGD stages at radii 2eps, 1.5eps, eps (reference lines 662-728).
+    Returns ``(x_adv, None, acc)`` with x_adv the lowest-pixel-accuracy iterate of the last stage."""
+    if norm != "Linf":
+        raise NotImplementedError()
+    logger = Logger(log_path)
+    n_iters, epss = largereps_schedule(n_iter, eps)
+    acc = torch.ones([x.shape[0]], device=x.device)
+    x_init = None
+    xc = x.detach().contiguous().float()
+    for s, (inner_it, inner_eps) in enumerate(zip(n_iters, epss)):
+        if x_init is not None:
+            x_init = N.linf_project(x_init.contiguous(), xc, float(inner_eps))  # reference lines 683-690
+        _, acc, _, x_init = apgd_train(model, xc, y, n_iter=inner_it, use_rs=use_rs, verbose=verbose, loss=loss,
+                                       eps=inner_eps, norm=norm, logger=logger, early_stop=early_stop,
+                                       track_loss=track_loss, y_target=None, ignore_index=ignore_index,
+                                       x_init=x_init, num_classes=num_classes, weights=weights,
+                                       noise=None if noises is None else noises[s])
+    return x_init, None, acc

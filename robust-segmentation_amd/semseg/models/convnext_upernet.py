@@ -1,0 +1,278 @@
+"""UperNet + ConvNeXt: the convolutional model family attacked by SEA / trained by PIR-AT.
+
+Own implementation for PyTorch-ROCm.  The attack hot path (semseg.attacker) only needs ``model(x) ->
+(B,C,H,W) logits``; this file exists so that the benchmark runs the architecture BASELINE.json names
+and so that published checkpoints load: parameter/buffer names and shapes follow the state-dict
+schema of the reference (semseg/models/uperforseg.py:382-404, backbones/convnext_orig.py:88-175;
+SURVEY Appendix B) exactly -- ``load_state_dict(strict=True)`` works both ways.
+
+The model stays on MIOpen / hipBLASLt (MFMA GEMMs and convolutions); nothing here is hand-written
+HIP.  Forward semantics mirror the reference: logits at 1/4 resolution, bilinear x4 to the input size
+(uperforseg.py:415-418), eval mode returns logits only, train mode returns (loss, logits) with the
+0.4-weighted auxiliary CE (uperforseg.py:421-439).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+# variant -> (depths, dims, aux-head input channels, stochastic-depth rate); convnext_orig.py:88-100
+CONVNEXT_SETTINGS = {
+    "T": ([3, 3, 9, 3], [96, 192, 384, 768], 384, 0.4),
+    "T_CVST": ([3, 3, 9, 3], [96, 192, 384, 768], 384, 0.4),
+    "T_CVST_ROB": ([3, 3, 9, 3], [96, 192, 384, 768], 384, 0.4),
+    "S_CVST": ([3, 3, 27, 3], [96, 192, 384, 768], 384, 0.3),
+    "S_CVST_ROB": ([3, 3, 27, 3], [96, 192, 384, 768], 384, 0.3),
+    "B": ([3, 3, 27, 3], [128, 256, 512, 1024], 512, 0.4),
+}
+
+
+class LayerNorm(nn.Module):
+    """LayerNorm over the channel dim for NHWC ("channels_last") or NCHW ("channels_first") tensors."""
+
+    def __init__(self, dim: int, eps: float = 1e-6, data_format: str = "channels_last"):
+        super().__init__()
+        if data_format not in ("channels_last", "channels_first"):
+            raise NotImplementedError(data_format)
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+        self.eps, self.data_format, self.dim = eps, data_format, dim
+
+    def forward(self, x):
+        if self.data_format == "channels_last":
+            return F.layer_norm(x, (self.dim,), self.weight, self.bias, self.eps)
+        y = F.layer_norm(x.permute(0, 2, 3, 1), (self.dim,), self.weight, self.bias, self.eps)
+        return y.permute(0, 3, 1, 2)
+
+
+class StochasticDepth(nn.Module):
+    def __init__(self, p: float):
+        super().__init__()
+        self.p = float(p)
+
+    def forward(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        keep = 1.0 - self.p
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+        return x * mask / keep
+
+
+class ConvStem(nn.Module):
+    """"CVST" stem: two stride-2 3x3 convs (3->48->96) each followed by channel LN + GELU."""
+
+    def __init__(self, width: int = 48):
+        super().__init__()
+        self.stem = nn.Sequential(
+            nn.Conv2d(3, width, 3, stride=2, padding=1), LayerNorm(width, data_format="channels_first"), nn.GELU(),
+            nn.Conv2d(width, 2 * width, 3, stride=2, padding=1), LayerNorm(2 * width, data_format="channels_first"),
+            nn.GELU())
+
+    def forward(self, x):
+        return self.stem(x)
+
+
+class Block(nn.Module):
+    """7x7 depthwise conv -> LN -> Linear(4x) -> GELU -> Linear -> layer scale -> residual."""
+
+    def __init__(self, dim: int, drop_path: float = 0.0, layer_scale_init_value: float = 1.0):
+        super().__init__()
+        self.dwconv = nn.Conv2d(dim, dim, 7, padding=3, groups=dim)
+        self.norm = LayerNorm(dim)
+        self.pwconv1 = nn.Linear(dim, 4 * dim)
+        self.act = nn.GELU()
+        self.pwconv2 = nn.Linear(4 * dim, dim)
+        self.gamma = nn.Parameter(layer_scale_init_value * torch.ones(dim)) if layer_scale_init_value > 0 else None
+        self.drop_path = StochasticDepth(drop_path) if drop_path > 0 else nn.Identity()
+
+    def forward(self, x):
+        y = self.dwconv(x).permute(0, 2, 3, 1)
+        y = self.pwconv2(self.act(self.pwconv1(self.norm(y))))
+        if self.gamma is not None:
+            y = self.gamma * y
+        return x + self.drop_path(y.permute(0, 3, 1, 2))
+
+
+class ConvNeXt(nn.Module):
+    def __init__(self, strr: str, in_chans: int = 3, layer_scale_init_value: float = 1.0, out_indices=(0, 1, 2, 3)):
+        super().__init__()
+        if strr not in CONVNEXT_SETTINGS:
+            raise AssertionError(f"ConvNeXt model name should be in {list(CONVNEXT_SETTINGS)}")
+        depths, dims, _, dpr = CONVNEXT_SETTINGS[strr]
+        self.variant = strr
+        self.downsample_layers = nn.ModuleList()
+        if "CVST" in strr:
+            self.downsample_layers.append(ConvStem())
+        else:
+            self.downsample_layers.append(nn.Sequential(
+                nn.Conv2d(in_chans, dims[0], 4, stride=4), LayerNorm(dims[0], data_format="channels_first")))
+        for i in range(3):
+            self.downsample_layers.append(nn.Sequential(
+                LayerNorm(dims[i], data_format="channels_first"), nn.Conv2d(dims[i], dims[i + 1], 2, stride=2)))
+        rates = torch.linspace(0, dpr, sum(depths)).tolist()
+        self.stages = nn.ModuleList()
+        k = 0
+        for i in range(4):
+            self.stages.append(nn.Sequential(*[
+                Block(dims[i], rates[k + j], layer_scale_init_value) for j in range(depths[i])]))
+            k += depths[i]
+        self.out_indices = tuple(out_indices)
+        for i in range(4):
+            self.add_module(f"norm{i}", LayerNorm(dims[i], data_format="channels_first"))
+        self.apply(self._init)
+
+    @staticmethod
+    def _init(m):
+        if isinstance(m, (nn.Conv2d, nn.Linear)):
+            nn.init.trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+
+    def forward(self, x):
+        feats = []
+        for i in range(4):
+            x = self.stages[i](self.downsample_layers[i](x))
+            if i in self.out_indices:
+                feats.append(getattr(self, f"norm{i}")(x))
+        return tuple(feats)
+
+
+class ConvModule(nn.Module):
+    """bias-free conv + BatchNorm + ReLU (uperforseg.py:119-146)."""
+
+    def __init__(self, cin, cout, kernel_size, padding=0, dilation=1):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, kernel_size, padding=padding, dilation=dilation, bias=False)
+        self.batch_norm = nn.BatchNorm2d(cout)
+        self.activation = nn.ReLU()
+
+    def forward(self, x):
+        return self.activation(self.batch_norm(self.conv(x)))
+
+
+def _up(x, size):
+    return F.interpolate(x, size=size, mode="bilinear", align_corners=False)
+
+
+class PyramidPooling(nn.Module):
+    """Children "0".."3", each Sequential-like [AdaptiveAvgPool2d(s), ConvModule] with children "0","1"."""
+
+    def __init__(self, scales, cin, cout):
+        super().__init__()
+        for i, s in enumerate(scales):
+            blk = nn.Module()
+            blk.add_module("0", nn.AdaptiveAvgPool2d(s))
+            blk.add_module("1", ConvModule(cin, cout, 1))
+            self.add_module(str(i), blk)
+        self.n = len(scales)
+
+    def forward(self, x):
+        outs = []
+        for i in range(self.n):
+            blk = getattr(self, str(i))
+            outs.append(_up(getattr(blk, "1")(getattr(blk, "0")(x)), x.shape[2:]))
+        return outs
+
+
+class UperNetHead(nn.Module):
+    def __init__(self, in_channels, cls, channels: int = 512, pool_scales=(1, 2, 3, 6)):
+        super().__init__()
+        self.in_channels = list(in_channels)
+        self.classifier = nn.Conv2d(channels, cls, 1)
+        self.psp_modules = PyramidPooling(pool_scales, self.in_channels[-1], channels)
+        self.bottleneck = ConvModule(self.in_channels[-1] + len(pool_scales) * channels, channels, 3, padding=1)
+        self.lateral_convs = nn.ModuleList(ConvModule(c, channels, 1) for c in self.in_channels[:-1])
+        self.fpn_convs = nn.ModuleList(ConvModule(channels, channels, 3, padding=1) for _ in self.in_channels[:-1])
+        self.fpn_bottleneck = ConvModule(len(self.in_channels) * channels, channels, 3, padding=1)
+
+    def init_weights(self):
+        self.apply(_head_init)
+
+    def forward(self, feats):
+        top = feats[-1]
+        lat = [conv(feats[i]) for i, conv in enumerate(self.lateral_convs)]
+        lat.append(self.bottleneck(torch.cat([top] + self.psp_modules(top), dim=1)))
+        for i in range(len(lat) - 1, 0, -1):
+            lat[i - 1] = lat[i - 1] + _up(lat[i], lat[i - 1].shape[2:])
+        outs = [self.fpn_convs[i](lat[i]) for i in range(len(lat) - 1)] + [lat[-1]]
+        outs = [outs[0]] + [_up(o, outs[0].shape[2:]) for o in outs[1:]]
+        return self.classifier(self.fpn_bottleneck(torch.cat(outs, dim=1)))
+
+
+class UperNetFCNHead(nn.Module):
+    def __init__(self, in_channels: int = 384, cls: int = 150, in_index: int = 2, channels: int = 256):
+        super().__init__()
+        self.in_index = in_index
+        self.convs = nn.Sequential(ConvModule(in_channels, channels, 3, padding=1))
+        self.classifier = nn.Conv2d(channels, cls, 1)
+
+    def init_weights(self):
+        self.apply(_head_init)
+
+    def forward(self, feats):
+        return self.classifier(self.convs(feats[self.in_index]))
+
+
+def _head_init(m):
+    if isinstance(m, (nn.Linear, nn.Conv2d)):
+        m.weight.data.normal_(mean=0.0, std=0.02)
+        if m.bias is not None:
+            m.bias.data.zero_()
+
+
+class UperNetForSemanticSegmentation(nn.Module):
+    """``UperNetForSemanticSegmentation("ConvNeXt-T_CVST", n_cls, pretrained)`` (uperforseg.py:382-404)."""
+
+    def __init__(self, backbone: str = "ConvNeXt-T_CVST", n_cls: int = 150, pretrained=None):
+        super().__init__()
+        _, variant = backbone.split("-")
+        self.backbone = ConvNeXt(variant)
+        dims, aux_in = CONVNEXT_SETTINGS[variant][1], CONVNEXT_SETTINGS[variant][2]
+        self.decode_head = UperNetHead(dims, n_cls)
+        self.auxiliary_head = UperNetFCNHead(aux_in, n_cls)
+        if pretrained is not None:
+            load_backbone_checkpoint(self.backbone, pretrained)
+            self.decode_head.init_weights()
+            self.auxiliary_head.init_weights()
+
+    def forward(self, input, lbl=None):
+        feats = self.backbone(input)
+        logits = _up(self.decode_head(feats), input.shape[2:])
+        loss = None
+        if lbl is not None:
+            aux = _up(self.auxiliary_head(feats), input.shape[2:])
+            loss = F.cross_entropy(logits, lbl, ignore_index=-1) + 0.4 * F.cross_entropy(aux, lbl, ignore_index=-1)
+        if self.training:
+            return loss, logits
+        return logits
+
+
+def load_backbone_checkpoint(backbone: ConvNeXt, path: str) -> None:
+    """Import an ImageNet ConvNeXt checkpoint into the backbone (convnext_orig.py:190-307): either the
+    official layout ({"model": {...}}, plain ConvNeXt) or the conv-stem robust-ImageNet layout
+    (``stem.stem.N``, ``stages.L.downsample.P``, ``stages.J.blocks.K.{conv_dw,norm,mlp.fc1,mlp.fc2}``)."""
+    ckpt = torch.load(path, map_location="cpu")
+    sd = backbone.state_dict()
+    new = {}
+    if "CVST" not in backbone.variant:
+        src = ckpt["model"]
+        for k in sd:
+            if k.startswith(("downsample_layers.", "stages.")) and k in src:
+                new[k] = src[k]
+    else:
+        src = {k.replace("module.", "").replace("base_model.", ""): v for k, v in ckpt.items()}
+        ren = {"dwconv": "conv_dw", "pwconv1": "mlp.fc1", "pwconv2": "mlp.fc2"}
+        for k in sd:
+            p = k.split(".")
+            if p[0] == "downsample_layers" and p[1] == "0":
+                new[k] = src[f"stem.stem.{p[3]}.{p[4]}"]
+            elif p[0] == "downsample_layers":
+                new[k] = src[f"stages.{p[1]}.downsample.{p[2]}.{p[3]}"]
+            elif p[0] == "stages":
+                tail = ".".join([ren.get(p[3], p[3])] + p[4:])
+                new[k] = src[f"stages.{p[1]}.blocks.{p[2]}.{tail}"]
+    missing = [k for k in sd if k.startswith(("downsample_layers.", "stages.")) and k not in new]
+    if missing:
+        raise KeyError(f"backbone checkpoint lacks {missing[:4]}...")
+    backbone.load_state_dict({**sd, **new})

@@ -1,0 +1,115 @@
+"""PIR-AT inner PGD attacks and confusion-matrix evaluation (counterpart of semseg/val.py).
+
+``Pgd_Attack_1`` / ``Pgd_Attack`` keep the reference's constructor and ``adv_attack`` signatures
+(val.py:130-218).  Each inner step is: model forward, ONE fused loss/gradient kernel on the logits
+(K2), input-gradient backward, ONE fused sign-step/projection kernel (K6).  Unlike the reference the
+backward is ``autograd.grad`` w.r.t. the input only: no parameter ``.grad`` is touched and, under DDP,
+no gradient all-reduce fires inside the inner loop.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _native as N
+from .metrics import Metrics
+
+__all__ = ["Pgd_Attack", "Pgd_Attack_1", "evaluate", "losses"]
+
+# name -> (K2 mode, per-image loss?)   (the `losses` table of val.py:121-127; none of them knows ignore labels)
+losses = {"pgd": (3, False), "mask-ce-avg": (0, True), "js-avg": (2, True)}
+
+
+def _labels(y):
+    return y.long().contiguous() if y.dtype not in (torch.int64, torch.int32, torch.int16, torch.uint8) else y.contiguous()
+
+
+def _fwd_grad(model, x_in, y, mode, scale, ws, out, dlogits):
+    """logits = model(x_in); returns (input gradient of sum of the loss, K2 stats, logits)."""
+    x_in = x_in.detach().requires_grad_(True)
+    with torch.enable_grad():
+        logits = model(x_in)
+    r = N.loss_fwd_bwd(logits.detach(), y, None, mode, mode, scale, want_grad=True, workspace=ws, out=out,
+                       dlogits=dlogits)
+    (g,) = torch.autograd.grad(logits, [x_in], grad_outputs=r["dlogits"])
+    return g.contiguous(), r, logits.detach()
+
+
+class Pgd_Attack_1:
+    """Random-start PGD, model sees X+delta unclamped (val.py:181-218)."""
+
+    def __init__(self, epsilon=4.0 / 255.0, alpha=1e-2, num_iter=2, los="pgd"):
+        self.epsilon, self.alpha, self.num_iter, self.los_name = epsilon, alpha, num_iter, los
+        self.mode, self.per_image = losses[los]
+
+    def adv_attack(self, model, X, y, delta0=None):
+        model.eval()
+        X = X.detach().contiguous().float()
+        B, HW = X.shape[0], X.shape[-2] * X.shape[-1]
+        y = _labels(y)
+        delta = torch.zeros_like(X).uniform_(-self.epsilon, self.epsilon) if delta0 is None else delta0.clone()
+        # F.cross_entropy(x, y) is the mean over all B*H*W pixels (val.py:122); the others are per-image means
+        scale = 1.0 / (HW if self.per_image else B * HW)
+        ws = N.loss_workspace(B, HW, X.device)
+        out = tuple(torch.empty(B, dtype=d, device=X.device) for d in (torch.float32, torch.float32, torch.int32))
+        x_in = X + delta
+        logits, dl = None, None
+        for _ in range(self.num_iter):
+            g, r, logits = _fwd_grad(model, x_in, y, self.mode, scale, ws, out, dl)
+            dl = r["dlogits"]
+            N.pgd_linf_step(X, delta, g, float(self.alpha), float(self.epsilon), delta_out=delta, x_in_out=x_in,
+                            clamp_input=False)
+        x_adv = (X + delta).clamp_(0.0, 1.0)
+        return x_adv.detach(), logits, None
+
+
+class Pgd_Attack:
+    """Zero-start PGD on the clamped input that keeps, per image, the perturbation obtained from the
+    step taken at its highest loss so far (val.py:130-178).  ``epsilon=`` is accepted as an alias of
+    ``eps=`` (tools/train_rob_seg.py:295-300 passes it)."""
+
+    def __init__(self, eps=4.0 / 255.0, alpha=1e-2, num_iter=2, los="pgd", epsilon=None):
+        self.epsilon = eps if epsilon is None else epsilon
+        self.alpha, self.num_iter, self.los_name = alpha, num_iter, los
+        self.mode, self.per_image = losses[los]
+        if not self.per_image:
+            # the reference indexes a scalar loss per image here and raises IndexError
+            raise ValueError("Pgd_Attack needs a per-image loss ('mask-ce-avg' or 'js-avg'); use Pgd_Attack_1 for 'pgd'")
+
+    def adv_attack(self, model, X, y, wt=None):
+        model.eval()
+        X = X.detach().contiguous().float()
+        B, HW = X.shape[0], X.shape[-2] * X.shape[-1]
+        y = _labels(y)
+        delta = torch.zeros_like(X)
+        best_delta = torch.zeros_like(X)
+        best = torch.zeros(B, device=X.device)
+        ws = N.loss_workspace(B, HW, X.device)
+        out = tuple(torch.empty(B, dtype=d, device=X.device) for d in (torch.float32, torch.float32, torch.int32))
+        x_in = X.clamp(0.0, 1.0)
+        dl = None
+        for _ in range(self.num_iter):
+            g, r, _ = _fwd_grad(model, x_in, y, self.mode, 1.0 / HW, ws, out, dl)
+            dl = r["dlogits"]
+            loss = r["loss_sum"] / HW
+            ind = loss >= best
+            best = torch.where(ind, loss, best)
+            N.pgd_linf_step(X, delta, g, float(self.alpha), float(self.epsilon), delta_out=delta, x_in_out=x_in,
+                            clamp_input=True)
+            best_delta = torch.where(ind.view(-1, 1, 1, 1), delta, best_delta)
+        return (X + best_delta).clamp_(0.0, 1.0).detach(), None, None
+
+
+@torch.no_grad()
+def evaluate(model, dataloader, device, cls, n_batches=-1):
+    """Confusion-matrix evaluation loop (val.py:14-32); same 7-tuple."""
+    model.eval()
+    metrics = Metrics(cls, -1, device)
+    for i, batch in enumerate(dataloader):
+        images, labels = batch[0].to(device), batch[1].to(device)
+        metrics.update(model(images), labels)  # argmax(softmax(z)) == argmax(z): the softmax pass is dropped
+        if i + 1 == n_batches:
+            break
+    ious, miou = metrics.compute_iou()
+    cla_acc, macc, aacc = metrics.compute_pixel_acc()
+    f1, mf1 = metrics.compute_f1()
+    return cla_acc, macc, aacc, f1, mf1, ious, miou

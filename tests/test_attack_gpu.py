@@ -1,0 +1,134 @@
+"""Device-resident APGD / PGD drivers against the reference's golden trajectories (`-m gpu`).
+
+The tiny models come from oracle/tiny_models.py (test infrastructure): PointwiseNet evaluates to
+bit-identical logits on CPU and GPU, TinyConvNet goes through MIOpen and differs in the last bits,
+so trajectories are compared like the oracle-vs-reference tests do: integer accuracy counts exact,
+float losses to 1e-4, iterates equal on all but a vanishing fraction of elements.
+"""
+import glob
+import os
+
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+from oracle.tiny_models import PointwiseNet, TinyConvNet
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def A():
+    from semseg import attacker
+    from semseg import _native
+    _native.lib()
+    return attacker
+
+
+def _g4_files():
+    return sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "g4_apgd_*_C*.npz")))
+
+
+def _frac_diff(a, b, tol=1e-6):
+    return ((a.cpu() - b).abs() > tol).float().mean().item()
+
+
+@pytest.mark.parametrize("name", _g4_files())
+def test_apgd_train_golden_trajectory(A, name):
+    g = load_golden(name)
+    _, _, netname, Cs, loss, n = name.split("_")
+    C, n_iter = int(Cs[1:]), int(n)
+    net = (TinyConvNet if netname == "conv" else PointwiseNet)(C, seed=C).cuda()
+    xb, acc, lb, xba = A.apgd_train(net, g["x"].cuda(), g["y"].cuda(), "Linf", g["eps"], n_iter=n_iter, use_rs=False,
+                                    loss=loss, track_loss="ce-avg", x_init=g["x_init"].cuda(), num_classes=C,
+                                    weights=g["w"].cuda(), early_stop=True, logger=A.Logger(None))
+    exact = netname == "pw"
+    if exact:
+        assert torch.equal(acc.cpu(), g["acc"])
+    else:
+        assert (acc.cpu() - g["acc"]).abs().max() <= 2.0 / 256  # at most two pixels of a 16x16 image flip
+    torch.testing.assert_close(lb.cpu(), g["loss_best"], rtol=1e-4, atol=1e-4)
+    lim = 0.002 if exact else 0.02
+    assert _frac_diff(xb, g["x_best"]) <= lim
+    assert _frac_diff(xba, g["x_best_adv"]) <= lim
+    assert (xba.cpu() - g["x"]).abs().max() <= g["eps"] + 1e-7
+
+
+EARLY = {
+    "a": (TinyConvNet, dict(seed=4, gain=3.0), "js-avg"),
+    "b": (TinyConvNet, dict(seed=5, gain=3.0), "mask-ce-avg"),
+    "c": (PointwiseNet, dict(seed=3, gain=8.0, bias=0.0), "mask-ce-avg"),
+}
+
+
+class _Counting(torch.nn.Module):
+    def __init__(self, net):
+        super().__init__()
+        self.net, self.calls = net, 0
+
+    def forward(self, x):
+        self.calls += 1
+        return self.net(x)
+
+
+@pytest.mark.parametrize("tag", sorted(EARLY))
+def test_apgd_early_stop_is_frozen_on_device(A, tag):
+    g = load_golden(f"g4_earlystop_{tag}")
+    Net, kw, loss = EARLY[tag]
+    net = _Counting(Net(5, **kw).cuda()).eval()
+    n_iter = int(g["n_iter"])
+    xb, acc, lb, xba = A.apgd_train(net, g["x"].cuda(), g["y"].cuda(), "Linf", g["eps"], n_iter=n_iter, loss=loss,
+                                    track_loss="ce-avg", early_stop=True, num_classes=5, poll_every=2)
+    assert acc.sum().item() == 0 and torch.equal(acc.cpu(), g["acc"])
+    torch.testing.assert_close(lb.cpu(), g["loss_best"], rtol=1e-4, atol=1e-4)
+    assert _frac_diff(xb, g["x_best"]) <= 0.02 and _frac_diff(xba, g["x_best_adv"]) <= 0.02
+    # the host left the loop early (it may run a few extra, frozen, iterations past the reference's break)
+    assert net.calls <= min(n_iter + 1, int(g["n_forward"]) + 6)
+    # never polling gives the same outputs: state is frozen on the device once the flag is up
+    net2 = Net(5, **kw).cuda()
+    xb2, acc2, lb2, xba2 = A.apgd_train(net2, g["x"].cuda(), g["y"].cuda(), "Linf", g["eps"], n_iter=n_iter, loss=loss,
+                                        track_loss="ce-avg", early_stop=True, num_classes=5, poll_every=10 ** 6)
+    assert torch.equal(xb, xb2) and torch.equal(xba, xba2) and torch.equal(lb, lb2) and torch.equal(acc, acc2)
+
+
+@pytest.mark.parametrize("C,loss", [(c, l) for c in (5, 21) for l in ("mask-ce-avg", "mask-ce-bal", "js-avg")])
+def test_apgd_largereps_golden(A, C, loss):
+    g = load_golden(f"g5_largereps_C{C}_{loss}")
+    net = TinyConvNet(C, seed=C + 50).cuda()
+    # the reference drew torch.rand_like(x) once per stage from the CPU generator seeded with `seed`
+    torch.manual_seed(int(g["seed"]))
+    noises = [torch.rand_like(g["x"]) for _ in range(3)]
+    xa, _, acc = A.apgd_largereps(net, g["x"].cuda().clone(), g["y"].cuda(), g["w"].cuda(), norm="Linf", eps=g["eps"],
+                                  n_iter=int(g["n_iter"]), n_restarts=1, use_rs=True, loss=loss, verbose=False,
+                                  track_loss="ce-avg", log_path=None, num_classes=C, early_stop=True, noises=noises)
+    assert (acc.cpu() - g["acc"]).abs().max() <= 2.0 / 256
+    assert _frac_diff(xa, g["x_adv"]) <= 0.03
+    assert (xa.cpu() - g["x"]).abs().max() <= g["eps"] + 1e-7
+
+
+def test_pgd_attacks_golden():
+    from semseg import val as V
+    g = load_golden("g6_pgd")
+    net = TinyConvNet(21, seed=9).cuda()
+    torch.manual_seed(int(g["seed"]))
+    delta0 = torch.zeros_like(g["x"]).uniform_(-4.0 / 255, 4.0 / 255)  # what the reference drew on CPU
+    xa1, logits1, _ = V.Pgd_Attack_1(epsilon=4.0 / 255, alpha=1e-2, num_iter=5, los="pgd").adv_attack(
+        net, g["x"].cuda(), g["y"].cuda(), delta0=delta0.cuda())
+    assert _frac_diff(xa1, g["x_adv_1"]) <= 0.02
+    torch.testing.assert_close(logits1.cpu(), g["logits_1"], rtol=1e-2, atol=5e-2)
+    for los, key in (("mask-ce-avg", "x_adv_mce"), ("js-avg", "x_adv_js")):
+        xa, _, _ = V.Pgd_Attack(eps=4.0 / 255, alpha=1e-2, num_iter=5, los=los).adv_attack(net, g["x"].cuda(), g["y"].cuda())
+        assert _frac_diff(xa, g[key]) <= 0.02, los
+    # the broken call sites of the reference are handled explicitly
+    V.Pgd_Attack(epsilon=4.0 / 255, los="mask-ce-avg")
+    with pytest.raises(ValueError):
+        V.Pgd_Attack(los="pgd")
+
+
+def test_no_cpu_fallback(A):
+    from semseg import _native
+    net = PointwiseNet(5, seed=1)
+    x = torch.rand(1, 3, 8, 8)
+    y = torch.zeros(1, 8, 8, dtype=torch.int64)
+    with pytest.raises(_native.SeaNativeError):
+        A.apgd_train(net, x, y, "Linf", 4.0 / 255, n_iter=2, loss="mask-ce-avg")

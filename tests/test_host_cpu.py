@@ -1,0 +1,113 @@
+"""CPU-side checks that run everywhere (`-m "not gpu"`): the C-ABI library loads and exports every
+symbol include/sea_hip.h declares, the host C++ greedy (K9) reproduces the reference bit for bit, the
+data-independent schedules match the oracle, and device-only entry points refuse CPU tensors."""
+import os
+import random
+import re
+import subprocess
+
+import pytest
+import torch
+
+from conftest import PKG, ROOT, load_golden
+from oracle import sea_oracle as O
+
+
+@pytest.fixture(scope="module")
+def native():
+    from semseg import _native
+    if not os.path.exists(_native.LIB_PATH):
+        import sys
+        sys.path.insert(0, PKG)
+        import build_native
+        build_native.build(verbose=False)
+    return _native
+
+
+def test_library_exports_every_declared_symbol(native):
+    header = open(os.path.join(ROOT, "include", "sea_hip.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|size_t|const char\*)\s+(sea_\w+)\s*\(", header, flags=re.M))
+    assert declared, "no declarations parsed"
+    out = subprocess.run(["nm", "-D", "--defined-only", native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (sea_\w+)", out))
+    assert declared <= exported, declared - exported
+    assert declared == set(native.EXPORTS)
+    lib = native.lib()  # binds every prototype; AttributeError on ABI drift
+    assert lib.sea_abi_version() == 1
+    assert b"gfx950" in lib.sea_build_info()
+    assert lib.sea_loss_workspace_bytes(8, 512 * 512) == 8 * 1024 * 16
+
+
+def test_header_is_plain_c():
+    subprocess.run(["gcc", "-std=c99", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", "sea_hip.h")], check=True)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_host_greedy_matches_reference_bit_for_bit(native, tag):
+    g = load_golden(f"g7_evalsea_{tag}")
+    random.seed(225)
+    st = random.getstate()
+    miou, sel, rounds, new_state = native.worst_miou_greedy(g["ints"], g["unions"], st[1])
+    assert miou == g["final_miou"]
+    ref, sel_ref, rounds_ref = O.worst_case_miou(g["ints"], g["unions"], rng=random.Random(225))
+    assert miou == ref and sel == sel_ref and rounds == rounds_ref
+    # the Mersenne-Twister state advanced exactly like `rounds` calls of random.shuffle
+    rr = random.Random(225)
+    for _ in range(rounds):
+        lst = list(range(g["ints"].shape[1]))
+        rr.shuffle(lst)
+    assert new_state == rr.getstate()[1]
+
+
+def test_host_greedy_random_tables(native):
+    gen = torch.Generator().manual_seed(5)
+    for N_, C_ in ((7, 4), (23, 9), (40, 21)):
+        tgt = torch.randint(0, C_, (N_, 10, 10), generator=gen)
+        preds = torch.stack([torch.where(torch.rand(tgt.shape, generator=gen) < 0.3 + 0.1 * a,
+                                         torch.randint(0, C_, tgt.shape, generator=gen), tgt) for a in range(3)])
+        ints, unis = O.per_image_tables(preds, tgt, C_)
+        seed = 1000 + N_
+        ref, sel_ref, r_ref = O.worst_case_miou(ints, unis, rng=random.Random(seed))
+        miou, sel, r, _ = native.worst_miou_greedy(ints, unis, random.Random(seed).getstate()[1])
+        assert miou == ref and sel == sel_ref and r == r_ref
+
+
+def test_schedules_match_oracle():
+    from semseg import attacker as A
+    for n in (1, 2, 3, 5, 10, 25, 90, 120, 300):
+        assert A.apgd_checkpoints(n) == O.checkpoints(n)
+        assert A.largereps_schedule(n, 4 / 255) == O.largereps_schedule(n, 4 / 255)
+    assert A.largereps_schedule(300, 1.0)[0] == [90, 90, 120]
+    assert list(A.apgd_checkpoints(90).items())[:3] == [(18, 19), (35, 17), (50, 15)]
+
+
+def test_device_entry_points_refuse_cpu_tensors(native):
+    x = torch.rand(1, 3, 8, 8)
+    with pytest.raises(native.SeaNativeError):
+        native.apgd_linf_step(x, x, x, x, torch.ones(1), 0.1, 1.0)
+    with pytest.raises(native.SeaNativeError):
+        native.loss_fwd_bwd(torch.rand(1, 5, 4, 4), torch.zeros(1, 4, 4, dtype=torch.int64), None, 0, 3, 1.0)
+
+
+def test_api_surface_matches_reference_signatures():
+    """names, positional order and defaults of the reference call surface"""
+    import inspect
+    from semseg import attacker as A, val as V, metrics as M, losses as L
+    from semseg.utils import utils as U
+    sig = inspect.signature(A.apgd_train)
+    assert list(sig.parameters)[:18] == ["model", "x", "y", "norm", "eps", "n_iter", "use_rs", "loss", "verbose",
+                                         "is_train", "early_stop", "track_loss", "logger", "y_target", "ignore_index",
+                                         "x_init", "num_classes", "weights"]
+    assert sig.parameters["n_iter"].default == 10 and sig.parameters["loss"].default == "ce"
+    sig = inspect.signature(A.apgd_largereps)
+    assert list(sig.parameters)[:17] == ["model", "x", "y", "weights", "norm", "eps", "n_iter", "loss", "verbose",
+                                         "n_restarts", "log_path", "early_stop", "eot_iter", "track_loss", "use_rs",
+                                         "ignore_index", "num_classes"]
+    assert sig.parameters["eps"].default == 8.0 / 255.0
+    assert set(A.criterion_dict) == {"ce", "ce-avg", "mask-ce-avg", "mask-ce-bal", "js-avg"}
+    assert list(inspect.signature(V.Pgd_Attack_1.__init__).parameters)[1:] == ["epsilon", "alpha", "num_iter", "los"]
+    assert list(inspect.signature(V.Pgd_Attack.__init__).parameters)[1:5] == ["eps", "alpha", "num_iter", "los"]
+    assert list(inspect.signature(M.Metrics.__init__).parameters)[1:] == ["num_classes", "ignore_label", "device"]
+    assert L.get_loss("CrossEntropy", -1, None).criterion.ignore_index == -1
+    assert len(U.ADE_WTS) == 151 and len(U.VOC_WTS) == 21
+    assert U.getModelName("UperNetForSemanticSegmentation", "ConvNeXt-T_CVST") == "UperNet_ConvNeXt-T_CVST"

@@ -1,0 +1,276 @@
+"""Parity of the HIP kernels (through the C ABI of libsea_hip.so) with the CPU oracle and with the
+golden vectors generated from the reference.  Needs a real MI355X: run with `-m gpu`.
+
+Bars: integer / index / byte results bit-exact; element-wise L-inf arithmetic bit-exact; float
+losses within 1e-4 (the tolerance of BASELINE.json's north_star), asserted tighter where the
+arithmetic allows.
+"""
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import sea_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+LOSS_ATOL = 1e-4  # north_star tolerance on float losses
+
+
+@pytest.fixture(scope="module")
+def N():
+    from semseg import _native
+    _native.lib()  # raises if the extension is missing: no silent fallback
+    return _native
+
+
+def dev(t):
+    return t.cuda() if isinstance(t, torch.Tensor) else t
+
+
+# ------------------------------------------------------------------------------------------------ K1/K5/K6
+def test_linf_kernels_golden_bit_exact(N):
+    g = load_golden("g2_linf")
+    for ci in range(5):
+        p = lambda k: g[f"c{ci}_{k}"]  # noqa: E731
+        out = N.apgd_linf_step(dev(p("x")), dev(p("x_adv")), dev(p("x_old")), dev(p("grad")), dev(p("step")),
+                               p("eps"), p("a"))
+        assert torch.equal(out.cpu(), p("out"))
+        assert torch.equal(N.linf_random_start(dev(p("x")), dev(p("u")), p("eps")).cpu(), p("rs"))
+        assert torch.equal(N.linf_project(dev(p("zz")), dev(p("x")), p("eps")).cpu(), p("proj"))
+        d = N.pgd_linf_step(dev(p("x")), dev(p("delta")), dev(p("grad")), p("alpha"), p("eps"))
+        assert torch.equal(d.cpu(), p("delta_out"))
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 16, 16), (3, 3, 33, 31), (1, 3, 7, 5), (8, 3, 512, 512)])
+def test_linf_kernels_vs_oracle(N, shape):
+    g = torch.Generator().manual_seed(sum(shape))
+    eps, a = 8.0 / 255, 0.75
+    x = torch.rand(shape, generator=g)
+    x_old = (x + eps * (2 * torch.rand(shape, generator=g) - 1)).clamp(0, 1)
+    x_adv = (x + eps * (2 * torch.rand(shape, generator=g) - 1)).clamp(0, 1)
+    grad = torch.randn(shape, generator=g)
+    grad[torch.rand(shape, generator=g) < 0.1] = 0
+    step = 2 * eps / (2.0 ** torch.arange(shape[0]).float())
+    ref = O.apgd_linf_step(x, x_adv, x_old, grad, step, eps, a)
+    out = N.apgd_linf_step(dev(x), dev(x_adv), dev(x_old), dev(grad), dev(step), eps, a)
+    assert torch.equal(out.cpu(), ref)
+    # properties that hold at any size: inside the eps-ball and the image box
+    assert (out.cpu() - x).abs().max() <= eps + 1e-7 and out.min() >= 0 and out.max() <= 1
+    u = torch.rand(shape, generator=g)
+    assert torch.equal(N.linf_random_start(dev(x), dev(u), eps).cpu(), O.linf_random_start(x, u, eps))
+    z = x + (x_adv - x) * 2.5
+    pr = N.linf_project(dev(z), dev(x), eps)
+    assert torch.equal(pr.cpu(), O.linf_project(z, x, eps))
+    assert torch.equal(N.linf_project(pr, dev(x), eps), pr)  # idempotent
+    delta = (torch.rand(shape, generator=g) * 2 - 1) * eps
+    xin = torch.empty(shape, device="cuda")
+    d = N.pgd_linf_step(dev(x), dev(delta), dev(grad), 1e-2, eps, x_in_out=xin, clamp_input=False)
+    dref = O.pgd_linf_step(x, delta, grad, 1e-2, eps)
+    assert torch.equal(d.cpu(), dref) and torch.equal(xin.cpu(), x + dref)
+
+
+# ------------------------------------------------------------------------------------------------ K2
+MODES = (("mask_ce_avg", 0), ("mask_ce_bal", 1), ("js_avg", 2), ("ce", 3))
+
+
+@pytest.mark.parametrize("C", [5, 21, 151])
+def test_loss_kernel_golden(N, C):
+    g = load_golden(f"g1_losses_C{C}")
+    logits, y, w = dev(g["logits"]), dev(g["y"]), dev(g["w"])
+    B, _, H, W = logits.shape
+    HW = H * W
+    for key, mode in MODES:
+        pred = torch.empty(B, H, W, dtype=torch.int64, device="cuda")
+        lpx = torch.empty(B, H, W, device="cuda")
+        r = N.loss_fwd_bwd(logits, y, w, mode, 3, 1.0 / HW, want_grad=True, pred=pred, loss_px=lpx)
+        torch.cuda.synchronize()
+        assert torch.equal(pred.cpu(), g["pred"])                                   # argmax: bit-exact
+        torch.testing.assert_close(lpx.cpu(), g[key + "_px"], rtol=2e-5, atol=2e-6)
+        torch.testing.assert_close((r["loss_sum"] / HW).cpu(), g[key + "_img"], rtol=2e-5, atol=LOSS_ATOL * 1e-2)
+        torch.testing.assert_close((r["track_sum"] / HW).cpu(), g["ce_img"], rtol=2e-5, atol=LOSS_ATOL * 1e-2)
+        torch.testing.assert_close(r["dlogits"].cpu(), g[key + "_grad"], rtol=1e-4, atol=2e-8)
+        n_ign = (g["y"] == -1).view(B, -1).sum(-1)
+        assert torch.equal(r["n_correct"].cpu().long().float() / HW, g["acc_step0"])
+        assert torch.equal((r["n_correct"].cpu().long() + n_ign).float() / HW, g["acc_loop"])
+
+
+def test_argmax_first_maximum(N):
+    g = load_golden("g1_argmax_ties")
+    z = dev(g["z"]).view(3, 4, 1, 1).contiguous()
+    y = torch.zeros(3, 1, 1, dtype=torch.int64, device="cuda")
+    pred = torch.empty(3, 1, 1, dtype=torch.int64, device="cuda")
+    N.loss_fwd_bwd(z, y, None, 3, 3, 1.0, want_grad=False, pred=pred)
+    assert torch.equal(pred.view(3).cpu(), g["arg"])
+
+
+def _rand_case(B, C, H, W, seed, ignore=0.05):
+    g = torch.Generator().manual_seed(seed)
+    logits = torch.randn(B, C, H, W, generator=g) * 3
+    y = torch.randint(0, C, (B, H, W), generator=g)
+    boost = (torch.rand(B, H, W, generator=g) < 0.7).float() * 6
+    logits.scatter_add_(1, y.unsqueeze(1), boost.unsqueeze(1))
+    # exact ties between two classes on some pixels exercise the tie-break
+    tie = torch.rand(B, H, W, generator=g) < 0.02
+    logits[:, 1][tie] = logits[:, 0][tie]
+    y[torch.rand(B, H, W, generator=g) < ignore] = -1
+    w = torch.rand(C, generator=g) + 0.01
+    return logits, y, w
+
+
+def _check_against_oracle(N, logits, y, w, mode, tmode, dl=None, **kw):
+    B, C, H, W = logits.shape
+    HW = H * W
+    ref = O.loss_fwd_bwd(logits.float(), y, w, mode, tmode, with_grad=True)
+    ld = dev(logits)
+    if kw.pop("channels_last", False):
+        ld = ld.contiguous(memory_format=torch.channels_last)
+    yd = kw.pop("y_dev", None)
+    yd = dev(y) if yd is None else yd
+    pred = torch.empty(B, H, W, dtype=kw.pop("pred_dtype", torch.int64), device="cuda")
+    r = N.loss_fwd_bwd(ld, yd, dev(w), mode, tmode, 1.0 / HW, want_grad=True, pred=pred, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(pred.cpu().long(), ref["pred"])
+    assert torch.equal(r["n_correct"].cpu().long(), ref["n_correct"])
+    torch.testing.assert_close((r["loss_sum"] / HW).cpu(), ref["loss_img"], rtol=3e-5, atol=LOSS_ATOL * 1e-2)
+    torch.testing.assert_close((r["track_sum"] / HW).cpu(), ref["track_img"], rtol=3e-5, atol=LOSS_ATOL * 1e-2)
+    got = r["dlogits"]
+    assert got.stride() == ld.stride()
+    tol = dict(rtol=1e-4, atol=2e-8 + 1e-6 / HW) if logits.dtype == torch.float32 else dict(rtol=2e-2, atol=1e-2 / HW)
+    torch.testing.assert_close(got.float().cpu(), ref["dlogits"], **tol)
+    return r
+
+
+@pytest.mark.parametrize("C", [2, 5, 19, 21, 27, 60, 100, 150, 151, 171, 200])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_loss_kernel_class_counts_sweep(N, C, mode):
+    """every register-kernel instantiation (exact-C and padded) and the streaming fallback (C=200)"""
+    logits, y, w = _rand_case(2, C, 16, 24, seed=C * 7 + mode)
+    _check_against_oracle(N, logits, y, w, mode, 3)
+
+
+@pytest.mark.parametrize("hw", [(16, 16), (33, 31), (17, 18), (1, 5), (64, 48)])
+@pytest.mark.parametrize("vec", [0, 1, 2, 4])
+def test_loss_kernel_shapes_and_vector_widths(N, hw, vec):
+    """odd H*W (473x473-like, no 16-byte alignment of the class planes) and forced pixels-per-lane"""
+    logits, y, w = _rand_case(3, 21, hw[0], hw[1], seed=hw[0] * 100 + hw[1])
+    _check_against_oracle(N, logits, y, w, 1, 3, force_vec=vec)
+
+
+@pytest.mark.parametrize("C", [21, 151])
+def test_loss_kernel_channels_last_and_label_types(N, C):
+    logits, y, w = _rand_case(2, C, 16, 16, seed=C)
+    _check_against_oracle(N, logits, y, w, 0, 3, channels_last=True)
+    y8 = torch.where(y < 0, torch.full_like(y, 255), y).to(torch.uint8)
+    _check_against_oracle(N, logits, y, w, 2, 3, y_dev=dev(y8), pred_dtype=torch.uint8)
+    _check_against_oracle(N, logits, y, w, 1, 1, y_dev=dev(y.to(torch.int16)), pred_dtype=torch.int16)
+    _check_against_oracle(N, logits, y, w, 3, 3, y_dev=dev(y.to(torch.int32)), pred_dtype=torch.int32)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_loss_kernel_half_precision_logits(N, dtype):
+    logits, y, w = _rand_case(2, 21, 16, 16, seed=3)
+    logits = logits.to(dtype)
+    _check_against_oracle(N, logits, y, w, 0, 3)
+    _check_against_oracle(N, logits, y, w, 2, 3)
+
+
+def test_loss_kernel_no_grad_variant_and_determinism(N):
+    logits, y, w = _rand_case(4, 21, 64, 64, seed=11)
+    a = N.loss_fwd_bwd(dev(logits), dev(y), dev(w), 1, 3, 1.0 / 4096, want_grad=False)
+    b = N.loss_fwd_bwd(dev(logits), dev(y), dev(w), 1, 3, 1.0 / 4096, want_grad=True)
+    assert a["dlogits"] is None
+    for k in ("loss_sum", "track_sum", "n_correct"):
+        assert torch.equal(a[k], b[k])
+    c = N.loss_fwd_bwd(dev(logits), dev(y), dev(w), 1, 3, 1.0 / 4096, want_grad=True)
+    assert torch.equal(b["dlogits"], c["dlogits"]) and torch.equal(b["loss_sum"], c["loss_sum"])
+
+
+def test_loss_kernel_js_is_nan_free_on_underflow(N):
+    """softmax underflow makes the reference's JS NaN; the closed form stays finite."""
+    z = torch.zeros(1, 5, 2, 2)
+    z[:, 0] = 200.0
+    y = torch.tensor([[[0, 1], [2, -1]]])
+    r = N.loss_fwd_bwd(dev(z), dev(y), None, 2, 2, 0.25, want_grad=True)
+    assert torch.isfinite(r["loss_sum"]).all() and torch.isfinite(r["dlogits"]).all()
+    assert r["loss_sum"].item() == pytest.approx(2 * 0.6931471805599453, rel=1e-5)
+
+
+def test_loss_kernel_full_size_voc_batch(N):
+    """BASELINE size B=8, C=21, 512x512 against the oracle, plus size-independent properties."""
+    B, C, H, W = 8, 21, 512, 512
+    logits, y, w = _rand_case(B, C, H, W, seed=2024)
+    r = _check_against_oracle(N, logits, y, w, 0, 3)
+    # softmax-gradient rows sum to zero per pixel; masked-out pixels have exactly zero gradient
+    dl = r["dlogits"]
+    assert dl.sum(1).abs().max().item() < 1e-9
+    masked = dev((O.argmax_first(logits) != y) | (y == -1))
+    assert (dl.abs().sum(1)[masked] == 0).all()
+    assert int(r["n_correct"].sum()) == int(((O.argmax_first(logits) == y)).sum())
+
+
+def test_differentiable_loss_wrappers(N):
+    """semseg.attacker's reduction='none' functions + autograd == the reference's (golden G1)."""
+    from semseg import attacker as A
+    g = load_golden("g1_losses_C21")
+    y, w = dev(g["y"]), dev(g["w"])
+    mask_bg = (y != -1).float()
+    for name, key in (("mask-ce-avg", "mask_ce_avg"), ("mask-ce-bal", "mask_ce_bal"), ("js-avg", "js_avg"), ("ce-avg", "ce")):
+        z = dev(g["logits"]).clone().requires_grad_(True)
+        lp = A.criterion_dict[name](z, y, w)
+        li = A.pixel_to_img_loss(lp, mask_bg)
+        (gr,) = torch.autograd.grad(li.sum(), [z])
+        torch.testing.assert_close(lp.detach().cpu(), g[key + "_px"], rtol=2e-5, atol=2e-6)
+        torch.testing.assert_close(li.detach().cpu(), g[key + "_img"], rtol=2e-5, atol=1e-6)
+        torch.testing.assert_close(gr.cpu(), g[key + "_grad"], rtol=1e-4, atol=2e-8)
+
+
+# ------------------------------------------------------------------------------------------------ K3
+@pytest.mark.parametrize("C", [5, 21])
+def test_counts_and_confusion_golden(N, C):
+    g = load_golden(f"g3_counts_C{C}")
+    pred, y = dev(g["pred"]), dev(g["y"])
+    hist = N.confusion(pred, y, C)
+    assert torch.equal(hist.cpu().float(), g["hist"])
+    inter, pc, tc = N.class_counts(pred, y, C, per_image=False, mask_pred=True)
+    h = hist.cpu()
+    assert torch.equal(inter.cpu(), h.diag()) and torch.equal(tc.cpu(), h.sum(1)) and torch.equal(pc.cpu(), h.sum(0))
+    from semseg import attacker as A
+    p2 = pred.clone()
+    m_acc, a_acc, m_iou = A.compute_iou_acc(p2, y, C)
+    assert torch.equal(p2.cpu(), g["pred_after"])
+    assert m_acc.item() == pytest.approx(g["m_acc"], rel=1e-6)
+    assert a_acc.item() == pytest.approx(g["a_acc"], rel=1e-6)
+    assert m_iou.item() == pytest.approx(g["m_iou"], rel=1e-6)
+    from semseg.metrics import Metrics
+    met = Metrics(C, -1, "cuda")
+    met.update(torch.nn.functional.one_hot(g["pred"], C).permute(0, 3, 1, 2).float().cuda(), y)
+    assert torch.equal(met.hist.cpu(), g["hist"])
+    ious, miou = met.compute_iou()
+    acc, macc, aacc = met.compute_pixel_acc()
+    f1, mf1 = met.compute_f1()
+    assert miou == g["miou"] and macc == g["macc"] and mf1 == g["mf1"]
+
+
+@pytest.mark.parametrize("C,shape,dt", [(151, (3, 40, 52), torch.int64), (21, (8, 512, 512), torch.uint8),
+                                        (300, (2, 16, 16), torch.int16)])
+def test_counts_vs_oracle(N, C, shape, dt):
+    g = torch.Generator().manual_seed(C)
+    pred = torch.randint(0, C, shape, generator=g)
+    y = torch.randint(0, C, shape, generator=g)
+    m = torch.rand(shape, generator=g) < 0.6
+    y[m] = pred[m]
+    y[torch.rand(shape, generator=g) < 0.05] = -1
+    conv = (lambda t: torch.where(t < 0, torch.full_like(t, 255), t).to(dt)) if dt == torch.uint8 else (lambda t: t.to(dt))
+    for per_image in (False, True):
+        for mask_pred in (False, True):
+            ref = O.class_counts(pred, y, C, per_image=per_image, mask_pred=mask_pred)
+            got = N.class_counts(dev(conv(pred)), dev(conv(y)), C, per_image=per_image, mask_pred=mask_pred)
+            for a, b in zip(got, ref):
+                assert torch.equal(a.cpu(), b)
+    assert torch.equal(N.confusion(dev(conv(pred)), dev(conv(y)), C).cpu(), O.confusion_matrix(pred, y, C))
+    # size-independent: every valid pixel is counted exactly once; accumulation is additive
+    out = N.class_counts(dev(conv(pred)), dev(conv(y)), C)
+    assert int(out[2].sum()) == int((y >= 0).sum())
+    N.class_counts(dev(conv(pred)), dev(conv(y)), C, out=out)
+    assert int(out[2].sum()) == 2 * int((y >= 0).sum())
+    assert torch.equal(N.count_ignored(dev(conv(y))).cpu().long(), (y == -1).view(shape[0], -1).sum(-1))

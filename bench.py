@@ -45,14 +45,15 @@ def build_case(rank, B, C, backbone, device):
     return model, x, y
 
 
-def cpu_baseline(C, backbone, loss, eps, B=2, n_iter=2):
-    """The oracle's APGD loop (the restated reference path) on the host cores, bounded sample."""
+def cpu_baseline(C, backbone, loss, eps, B=1, n_iter=1):
+    """The oracle's APGD loop (the restated reference path) on the host cores, bounded sample
+    (about 10-30 s): step 0 + n_iter loop iterations on B images."""
     from oracle import sea_oracle as O
     from semseg.models import UperNetForSemanticSegmentation
     from semseg.utils.utils import ADE_WTS, VOC_WTS
     torch.manual_seed(0)
     model = UperNetForSemanticSegmentation(backbone, C, None).eval()
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)  # more threads than that slow PyTorch-CPU convolutions down
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(1234)
     x = torch.rand(B, 3, 512, 512, generator=g)
@@ -62,10 +63,11 @@ def cpu_baseline(C, backbone, loss, eps, B=2, n_iter=2):
     t0 = time.perf_counter()
     O.apgd_train(model, x, y, eps=eps, n_iter=n_iter, loss=loss, track_loss="ce-avg", weights=w, early_stop=True)
     dt = time.perf_counter() - t0
-    # (1 + n_iter) forwards and n_iter backwards ran; count loop iterations like the GPU metric does
-    return {"value": B * n_iter / dt, "unit": "image-iterations/s", "cores": cores, "kind": "port",
-            "sample": f"oracle apgd_train, UperNet-{backbone}, B={B}x512x512, C={C}, n_iter={n_iter} "
-                      f"(+ step 0), {loss}, {dt:.1f} s wall"}
+    # (1 + n_iter) forwards and n_iter backwards ran (the last iteration has no backward, like the
+    # reference); every pass is counted as an iteration here, which favours the CPU number
+    return {"value": B * (n_iter + 1) / dt, "unit": "image-iterations/s", "cores": cores, "kind": "port",
+            "sample": f"oracle apgd_train (PyTorch-CPU restatement of the reference loop), UperNet-{backbone}, "
+                      f"B={B}x512x512, C={C}, step 0 + {n_iter} iteration(s), {loss}, {dt:.1f} s wall"}
 
 
 def main():

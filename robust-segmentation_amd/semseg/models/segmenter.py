@@ -1,0 +1,263 @@
+"""Segmenter (ViT encoder + mask-transformer decoder): the transformer model family attacked by SEA.
+
+Own implementation for PyTorch-ROCm with the reference's state-dict schema (185
+tensors for ViT-S/16 with 151 classes; semseg/models/segmenter.py:196-353,
+backbones/vit_encoder.py:84-294, heads/segmenter_decoder.py:30-99).  Attention goes through
+``F.scaled_dot_product_attention`` (fused kernel on ROCm) instead of materialising softmax(QK^T).
+Forward semantics: pad to a multiple of 16, encode, drop the class token, decode to (B,n_cls,H/16,W/16)
+masks, bilinear x16 back to the padded size, crop.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .convnext_upernet import StochasticDepth
+
+
+def _init(m):
+    if isinstance(m, nn.Linear):
+        nn.init.trunc_normal_(m.weight, std=0.02)
+        if m.bias is not None:
+            nn.init.zeros_(m.bias)
+    elif isinstance(m, nn.LayerNorm):
+        nn.init.zeros_(m.bias)
+        nn.init.ones_(m.weight)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, heads, dropout):
+        super().__init__()
+        self.heads = heads
+        self.scale = (dim // heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3)
+        self.attn_drop = nn.Dropout(dropout)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(dropout)
+
+    def forward(self, x):
+        B, T, D = x.shape
+        q, k, v = self.qkv(x).reshape(B, T, 3, self.heads, D // self.heads).permute(2, 0, 3, 1, 4)
+        p = self.attn_drop.p if self.training else 0.0
+        y = F.scaled_dot_product_attention(q, k, v, dropout_p=p, scale=self.scale)
+        return self.proj_drop(self.proj(y.transpose(1, 2).reshape(B, T, D)))
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, hidden, dropout):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(hidden, dim)
+        self.drop = nn.Dropout(dropout)
+
+    def forward(self, x):
+        return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+
+
+class Block(nn.Module):
+    def __init__(self, dim, heads, mlp_dim, dropout, drop_path):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self.attn = Attention(dim, heads, dropout)
+        self.mlp = FeedForward(dim, mlp_dim, dropout)
+        self.drop_path = StochasticDepth(drop_path) if drop_path > 0.0 else nn.Identity()
+
+    def forward(self, x):
+        x = x + self.drop_path(self.attn(self.norm1(x)))
+        return x + self.drop_path(self.mlp(self.norm2(x)))
+
+
+class PatchEmbedding(nn.Module):
+    def __init__(self, image_size, patch_size, embed_dim, channels):
+        super().__init__()
+        if image_size[0] % patch_size or image_size[1] % patch_size:
+            raise ValueError("image dimensions must be divisible by the patch size")
+        self.image_size = image_size
+        self.grid_size = (image_size[0] // patch_size, image_size[1] // patch_size)
+        self.num_patches = self.grid_size[0] * self.grid_size[1]
+        self.patch_size = patch_size
+        self.proj = nn.Conv2d(channels, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+    def forward(self, im):
+        return self.proj(im).flatten(2).transpose(1, 2)
+
+
+def resize_pos_embed(posemb, grid_old, grid_new, num_extra_tokens):
+    tok, grid = posemb[:, :num_extra_tokens], posemb[0, num_extra_tokens:]
+    if grid_old is None:
+        gh = gw = int(math.sqrt(len(grid)))
+    else:
+        gh, gw = grid_old
+    grid = grid.reshape(1, gh, gw, -1).permute(0, 3, 1, 2)
+    grid = F.interpolate(grid, size=grid_new, mode="bilinear")
+    grid = grid.permute(0, 2, 3, 1).reshape(1, grid_new[0] * grid_new[1], -1)
+    return torch.cat([tok, grid], dim=1)
+
+
+class VisionTransformer(nn.Module):
+    def __init__(self, image_size, patch_size, n_layers, d_model, d_ff, n_heads, n_cls, dropout=0.1,
+                 drop_path_rate=0.1, distilled=False, channels=3):
+        super().__init__()
+        self.patch_embed = PatchEmbedding(image_size, patch_size, d_model, channels)
+        self.patch_size, self.n_layers, self.d_model, self.d_ff, self.n_heads = patch_size, n_layers, d_model, d_ff, n_heads
+        self.n_cls, self.distilled = n_cls, distilled
+        self.dropout = nn.Dropout(dropout)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, d_model))
+        extra = 2 if distilled else 1
+        if distilled:
+            self.dist_token = nn.Parameter(torch.zeros(1, 1, d_model))
+        self.pos_embed = nn.Parameter(torch.randn(1, self.patch_embed.num_patches + extra, d_model))
+        if distilled:
+            self.head_dist = nn.Linear(d_model, n_cls)
+        rates = torch.linspace(0, drop_path_rate, n_layers).tolist()
+        self.blocks = nn.ModuleList(Block(d_model, n_heads, d_ff, dropout, rates[i]) for i in range(n_layers))
+        self.norm = nn.LayerNorm(d_model)
+        self.head = nn.Linear(d_model, n_cls)
+        nn.init.trunc_normal_(self.pos_embed, std=0.02)
+        nn.init.trunc_normal_(self.cls_token, std=0.02)
+        if distilled:
+            nn.init.trunc_normal_(self.dist_token, std=0.02)
+        self.apply(_init)
+
+    def no_weight_decay(self):
+        return {"pos_embed", "cls_token", "dist_token"}
+
+    def forward(self, im, pre_neck=False):
+        B, _, H, W = im.shape
+        x = self.patch_embed(im)
+        toks = [self.cls_token.expand(B, -1, -1)]
+        if self.distilled:
+            toks.append(self.dist_token.expand(B, -1, -1))
+        x = torch.cat(toks + [x], dim=1)
+        pos = self.pos_embed
+        if x.shape[1] != pos.shape[1]:
+            pos = resize_pos_embed(pos, self.patch_embed.grid_size, (H // self.patch_size, W // self.patch_size),
+                                   1 + int(self.distilled))
+        x = self.dropout(x + pos)
+        for blk in self.blocks:
+            x = blk(x)
+        x = self.norm(x)
+        if pre_neck:
+            return x
+        if self.distilled:
+            return (self.head(x[:, 0]) + self.head_dist(x[:, 1])) / 2
+        return self.head(x[:, 0])
+
+
+class MaskTransformer(nn.Module):
+    def __init__(self, n_cls, patch_size, d_encoder, n_layers, n_heads, d_model, d_ff, drop_path_rate, dropout):
+        super().__init__()
+        self.d_encoder, self.patch_size, self.n_layers, self.n_cls = d_encoder, patch_size, n_layers, n_cls
+        self.d_model, self.d_ff = d_model, d_ff
+        self.scale = d_model ** -0.5
+        rates = torch.linspace(0, drop_path_rate, n_layers).tolist()
+        self.blocks = nn.ModuleList(Block(d_model, n_heads, d_ff, dropout, rates[i]) for i in range(n_layers))
+        self.cls_emb = nn.Parameter(torch.randn(1, n_cls, d_model))
+        self.proj_dec = nn.Linear(d_encoder, d_model)
+        self.proj_patch = nn.Parameter(self.scale * torch.randn(d_model, d_model))
+        self.proj_classes = nn.Parameter(self.scale * torch.randn(d_model, d_model))
+        self.decoder_norm = nn.LayerNorm(d_model)
+        self.mask_norm = nn.LayerNorm(n_cls)
+        self.apply(_init)
+        nn.init.trunc_normal_(self.cls_emb, std=0.02)
+
+    def no_weight_decay(self):
+        return {"cls_emb"}
+
+    def forward(self, x, im_size):
+        gs = im_size[0] // self.patch_size
+        x = torch.cat((self.proj_dec(x), self.cls_emb.expand(x.size(0), -1, -1)), 1)
+        for blk in self.blocks:
+            x = blk(x)
+        x = self.decoder_norm(x)
+        patches, cls_feat = x[:, :-self.n_cls] @ self.proj_patch, x[:, -self.n_cls:] @ self.proj_classes
+        patches = patches / patches.norm(dim=-1, keepdim=True)
+        cls_feat = cls_feat / cls_feat.norm(dim=-1, keepdim=True)
+        masks = self.mask_norm(patches @ cls_feat.transpose(1, 2))           # (B, h*w, n_cls)
+        return masks.transpose(1, 2).reshape(x.size(0), self.n_cls, gs, -1)   # b (h w) n -> b n h w
+
+
+class DecoderLinear(nn.Module):
+    def __init__(self, n_cls, patch_size, d_encoder):
+        super().__init__()
+        self.d_encoder, self.patch_size, self.n_cls = d_encoder, patch_size, n_cls
+        self.head = nn.Linear(d_encoder, n_cls)
+        self.apply(_init)
+
+    def no_weight_decay(self):
+        return set()
+
+    def forward(self, x, im_size):
+        gs = im_size[0] // self.patch_size
+        return self.head(x).transpose(1, 2).reshape(x.size(0), self.n_cls, gs, -1)
+
+
+class SegMenter(nn.Module):
+    def __init__(self, encoder, decoder, n_cls, backbone):
+        super().__init__()
+        self.n_cls, self.patch_size, self.encoder, self.decoder, self.backbone = n_cls, 16, encoder, decoder, backbone
+
+    def no_weight_decay(self):
+        return {"encoder." + k for k in self.encoder.no_weight_decay()} | {"decoder." + k for k in self.decoder.no_weight_decay()}
+
+    def forward(self, im):
+        H0, W0 = im.shape[2:]
+        ph, pw = (-H0) % self.patch_size, (-W0) % self.patch_size
+        if ph or pw:
+            im = F.pad(im, (0, pw, 0, ph), value=0)
+        H, W = im.shape[2:]
+        x = self.encoder(im, pre_neck=True)
+        x = x[:, 0 if "SAM" in self.backbone else 1 + int(self.encoder.distilled):]
+        masks = F.interpolate(self.decoder(x, (H, W)), size=(H, W), mode="bilinear")
+        return masks[:, :, :H0, :W0] if (ph or pw) else masks
+
+
+def create_vit(model_cfg, pretrained=None):
+    cfg = dict(model_cfg)
+    cfg.pop("backbone", None)
+    cfg.pop("normalization", None)
+    cfg["n_cls"] = 1000
+    cfg["d_ff"] = 4 * cfg["d_model"]
+    model = VisionTransformer(**cfg)
+    if pretrained:
+        ckpt = torch.load(pretrained, map_location="cpu")
+        ckpt = {k.replace("model.", "").replace("module.", ""): v for k, v in ckpt.items()}
+        for k in ("base_normalize.mean", "base_normalize.std"):
+            ckpt.pop(k, None)
+        ckpt = {k.replace("base_", ""): v for k, v in ckpt.items()}
+        own = model.state_dict()
+        if "pos_embed" in ckpt and ckpt["pos_embed"].shape != own["pos_embed"].shape:
+            n_extra = 1 + int(model.distilled)
+            ckpt["pos_embed"] = resize_pos_embed(ckpt["pos_embed"], None, model.patch_embed.grid_size, n_extra)
+        model.load_state_dict({k: v for k, v in ckpt.items() if k in own and v.shape == own[k].shape}, strict=False)
+    return model
+
+
+def create_decoder(encoder, decoder_cfg, backbone):
+    cfg = dict(decoder_cfg)
+    name = cfg.pop("name")
+    cfg["d_encoder"] = 768 if "SAM" in backbone else 384
+    cfg["patch_size"] = 16
+    if "linear" in name:
+        return DecoderLinear(**cfg)
+    if name == "mask_transformer":
+        dim = cfg["d_encoder"]
+        cfg.update(n_heads=dim // 64, d_model=dim, d_ff=4 * dim)
+        return MaskTransformer(**cfg)
+    raise ValueError(f"Unknown decoder: {name}")
+
+
+def create_segmenter(model_cfg, pretrained=None, backbone="vit_small_patch16_224"):
+    """``create_segmenter(model_cfg, pretrained, backbone)`` (segmenter.py:344-353).  ``pretrained=None``
+    skips the ImageNet checkpoint import (the reference always calls torch.load)."""
+    cfg = dict(model_cfg)
+    dec = dict(cfg.pop("decoder"))
+    dec["n_cls"] = cfg["n_cls"]
+    encoder = create_vit(cfg, pretrained)
+    decoder = create_decoder(encoder, dec, backbone=backbone)
+    return SegMenter(encoder, decoder, n_cls=cfg["n_cls"], backbone=backbone)

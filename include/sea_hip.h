@@ -177,6 +177,16 @@ int sea_worst_miou_greedy(const float* ints, const float* unions, int A, int N, 
                           uint32_t* mt_state, int n_rounds, double* miou, int32_t* selected,
                           int32_t* rounds_run);
 
+/* ------------------------------------------------------------------------------------------------
+ * M1  (model side) depthwise 7x7 convolution of the ConvNeXt block, stride 1, pad 3, fp32
+ * NCHW: forward (flip=0, F.conv2d semantics incl. bias) and backward-data (flip=1: pass dy as x, bias
+ * ignored).  Replaces the MIOpen/CK grouped convolution behind semseg/models/backbones/
+ * convnext_orig.py:55-57, 75 - an HBM-bound stencil that the library runs ~25x below the roofline.
+ *   x, y: (B*C, H, W) planes; w: (C,1,7,7); bias: (C) or NULL.
+ */
+int sea_dwconv7x7(const float* x, const float* w, const float* bias, float* y, int B, int C, int H,
+                  int W, int flip, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

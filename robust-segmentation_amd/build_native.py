@@ -29,6 +29,7 @@ SOURCES = [
     ("apgd_control.hip", ["-ffp-contract=off"]),
     ("loss_kernels.hip", []),
     ("stats_kernels.hip", []),
+    ("dwconv_kernels.hip", []),
     ("greedy_host.cpp", ["-ffp-contract=off"]),
     ("api_misc.cpp", []),
 ]

@@ -1,0 +1,108 @@
+// Depthwise 7x7 convolution (stride 1, pad 3, one filter per channel), fp32 NCHW: forward and
+// backward-data of the ConvNeXt block's spatial mixing (reference convnext_orig.py:55-57).
+//
+// Why it is here: MIOpen/CK run this layer at 2-4 TF/s (0.5 ms for 8x96x128x128) although it is a pure
+// HBM-bound stencil (read x once, write y once: 100 MB -> ~17 us at the measured copy ceiling).  It is
+// ~10 % of an APGD step on UperNet-ConvNeXt-T.  backward-data of a stride-1 depthwise convolution is the
+// same stencil with the filter flipped, so one kernel serves both directions.
+//
+// Mapping: one workgroup = one 32x32 output tile of one (image, channel) plane; the 38x38 input patch
+// (3-pixel halo) is staged in LDS once (zero padded), each lane produces a 1x4 strip: per filter row it
+// reads 10 consecutive floats from LDS (2 x ds_read_b128 + 1 x ds_read_b64) for 28 FMAs.  The 49
+// filter taps are wave-uniform (one channel per workgroup) and live in SGPRs.
+#include "sea_common.h"
+
+namespace sea {
+
+constexpr int DW_T = 32;          // output tile edge
+constexpr int DW_K = 7, DW_P = 3;
+constexpr int DW_IN = DW_T + DW_K - 1;  // 38
+constexpr int DW_LD = 40;               // LDS row stride in floats (16-byte aligned rows)
+
+template <bool FLIP, bool BIAS>
+__global__ __launch_bounds__(256) void dwconv7x7_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y,
+                                                        int C, int H, int W, int tiles_x) {
+  __shared__ __attribute__((aligned(16))) float tile[DW_IN * DW_LD];
+  const int plane = blockIdx.y;              // b*C + c
+  const int c = plane % C;
+  const int ty0 = (blockIdx.x / tiles_x) * DW_T, tx0 = (blockIdx.x % tiles_x) * DW_T;
+  const float* xp = x + (int64_t)plane * H * W;
+  // stage the input patch (zero outside the image)
+  for (int i = threadIdx.x; i < DW_IN * DW_IN; i += 256) {
+    const int r = i / DW_IN, q = i - r * DW_IN;
+    const int gy = ty0 + r - DW_P, gx = tx0 + q - DW_P;
+    float v = 0.f;
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = xp[(int64_t)gy * W + gx];
+    tile[r * DW_LD + q] = v;
+  }
+  // filter taps: uniform per workgroup -> scalar loads
+  float wt[DW_K * DW_K];
+#pragma unroll
+  for (int i = 0; i < DW_K * DW_K; ++i) wt[i] = w[c * DW_K * DW_K + (FLIP ? (DW_K * DW_K - 1 - i) : i)];
+  __syncthreads();
+
+  const int ly = threadIdx.x >> 3, lx = (threadIdx.x & 7) * 4;  // 32 rows x 8 strips of 4
+  float acc[4];
+  const float b0 = BIAS ? bias[c] : 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = b0;
+#pragma unroll
+  for (int ky = 0; ky < DW_K; ++ky) {
+    const float* row = tile + (ly + ky) * DW_LD + lx;
+    const float4 a = *reinterpret_cast<const float4*>(row);
+    const float4 b = *reinterpret_cast<const float4*>(row + 4);
+    const float2 d = *reinterpret_cast<const float2*>(row + 8);
+    const float in[10] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, d.x, d.y};
+#pragma unroll
+    for (int kx = 0; kx < DW_K; ++kx) {
+      const float wv = wt[ky * DW_K + kx];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = fmaf(in[j + kx], wv, acc[j]);
+    }
+  }
+  const int gy = ty0 + ly, gx = tx0 + lx;
+  if (gy < H) {
+    float* yp = y + (int64_t)plane * H * W + (int64_t)gy * W + gx;
+    if (gx + 3 < W && ((((uintptr_t)yp) & 15) == 0)) {
+      *reinterpret_cast<float4*>(yp) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (gx + j < W) yp[j] = acc[j];
+    }
+  }
+}
+
+}  // namespace sea
+
+using namespace sea;
+
+// x, y: (planes = B*C, H, W) contiguous fp32; w: (C,1,7,7); bias: (C) or NULL.
+// flip=0: forward cross-correlation (F.conv2d semantics); flip=1: backward-data (pass dy as x).
+extern "C" int sea_dwconv7x7(const float* x, const float* w, const float* bias, float* y, int B, int C, int H, int W,
+                             int flip, void* stream) {
+  SEA_CHECK_ARG(x && w && y && B > 0 && C > 0 && H > 0 && W > 0);
+  const int64_t planes = (int64_t)B * C;
+  SEA_CHECK_ARG(planes <= 65535 * 16);
+  const int tiles_x = (W + DW_T - 1) / DW_T, tiles_y = (H + DW_T - 1) / DW_T;
+  SEA_CHECK_ARG(planes <= 2147483647 / 1 && (int64_t)tiles_x * tiles_y <= 2147483647);
+  // grid.y is limited to 65535: fold planes beyond that into several launches
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t chunk = 65535;
+  for (int64_t p0 = 0; p0 < planes; p0 += chunk) {
+    const int np = (int)((planes - p0) < chunk ? (planes - p0) : chunk);
+    // plane index p0+blockIdx.y must map to channel (p0 + y) % C: keep p0 a multiple of C
+    SEA_CHECK_ARG(p0 % C == 0 || planes <= chunk);
+    dim3 grid(tiles_x * tiles_y, np);
+    const float* xs = x + p0 * H * W;
+    float* ys = y + p0 * H * W;
+    if (flip)
+      hipLaunchKernelGGL((dwconv7x7_kernel<true, false>), grid, dim3(256), 0, s, xs, w, (const float*)nullptr, ys, C, H, W, tiles_x);
+    else if (bias)
+      hipLaunchKernelGGL((dwconv7x7_kernel<false, true>), grid, dim3(256), 0, s, xs, w, bias, ys, C, H, W, tiles_x);
+    else
+      hipLaunchKernelGGL((dwconv7x7_kernel<false, false>), grid, dim3(256), 0, s, xs, w, (const float*)nullptr, ys, C, H, W, tiles_x);
+  }
+  SEA_RETURN_LAST();
+}

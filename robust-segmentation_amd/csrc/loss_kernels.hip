@@ -139,8 +139,10 @@ __device__ __forceinline__ void block_reduce_store(float ls, float ts, int nc, B
 //    (one per compare) and spill them.
 //  * the label compares of the gradient pass use an opaque copy of the label so they are not CSE'd
 //    with those of the z_y select (same reason).
-template <typename T, int CPAD, int VEC, bool GRAD, bool EXACT>
-__global__ __launch_bounds__(256) void loss_nchw_reg(const T* __restrict__ logits, const void* __restrict__ y,
+// TUNE bits (benchmark variants): 1 = non-temporal gradient stores, 2 = non-temporal logit loads,
+// 4 = ask for 4 waves/SIMD (<= 128 VGPRs)
+template <typename T, int CPAD, int VEC, bool GRAD, bool EXACT, int TUNE = 0>
+__global__ __launch_bounds__(256, (TUNE & 4) ? 4 : 1) void loss_nchw_reg(const T* __restrict__ logits, const void* __restrict__ y,
                                                      int y_bytes, const float* __restrict__ w, int mode,
                                                      int track_mode, int C, int64_t HW, float gscale,
                                                      T* __restrict__ dlogits, void* __restrict__ pred,
@@ -171,7 +173,11 @@ __global__ __launch_bounds__(256) void loss_nchw_reg(const T* __restrict__ logit
 #pragma unroll
     for (int c = 0; c < CPAD; ++c) {
       if (EXACT || c < C) {
-        const P p = *reinterpret_cast<gptr<P>>(plane + lane_off);
+        P p;
+        if (TUNE & 2)
+          p = __builtin_nontemporal_load(reinterpret_cast<gptr<P>>(plane + lane_off));
+        else
+          p = *reinterpret_cast<gptr<P>>(plane + lane_off);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) z[c][v] = Elem<T>::to_f(vec_get<R, VEC>(p, v));
       }
@@ -267,7 +273,10 @@ __global__ __launch_bounds__(256) void loss_nchw_reg(const T* __restrict__ logit
             const float g = A[v] * z[c][v];
             vec_set<R, VEC>(p, v, Elem<T>::from_f((lab2[v] == c) ? g - K[v] : g));
           }
-          *reinterpret_cast<gptr_w<P>>(gplane + lane_off) = p;
+          if (TUNE & 1)
+            __builtin_nontemporal_store(p, reinterpret_cast<gptr_w<P>>(gplane + lane_off));
+          else
+            *reinterpret_cast<gptr_w<P>>(gplane + lane_off) = p;
         }
         gplane += plane_bytes;
         asm volatile("" : "+s"(gplane));
@@ -539,8 +548,35 @@ static int dispatch_nchw(const LossArgs& a, bool vec4_ok, bool vec2_ok, int* vec
     *vec_used = V;           \
     return 0;                \
   } while (0)
-  // force_vec: 0 = heuristic, 1/2/4 = benchmark override (falls back when alignment forbids it)
-  const int fv = a.force_vec;
+  // force_vec: low 4 bits 0 = heuristic, 1/2/4 = pixels per lane; bits 4.. = TUNE variant (fp32 C=21/151 only)
+  const int fv = a.force_vec & 15;
+  const int tune = a.force_vec >> 4;
+  if (tune && a.dlogits && sizeof(T) == 4) {
+    dim3 block(256);
+#define SEA_TUNED(CP, V, TU)                                                                                         \
+  do {                                                                                                               \
+    dim3 grid(tiles_for(a.HW, V), a.B);                                                                              \
+    hipLaunchKernelGGL((loss_nchw_reg<T, CP, V, true, true, TU>), grid, block, 0, a.s, (const T*)a.logits, a.y,      \
+                       a.y_bytes, a.w, a.mode, a.track_mode, a.C, a.HW, a.gscale, (T*)a.dlogits, a.pred,             \
+                       a.pred_bytes, a.loss_px, a.partials);                                                         \
+    *vec_used = V;                                                                                                   \
+    return 0;                                                                                                        \
+  } while (0)
+    if (C == 21 && vec4_ok) {
+      if (tune == 1) SEA_TUNED(21, 4, 1);
+      if (tune == 2) SEA_TUNED(21, 4, 2);
+      if (tune == 3) SEA_TUNED(21, 4, 3);
+      if (tune == 4) SEA_TUNED(21, 4, 4);
+      if (tune == 5) SEA_TUNED(21, 4, 5);
+      if (tune == 7) SEA_TUNED(21, 4, 7);
+    }
+    if (C == 151) {
+      if (tune == 1) SEA_TUNED(151, 1, 1);
+      if (tune == 2) SEA_TUNED(151, 1, 2);
+      if (tune == 3) SEA_TUNED(151, 1, 3);
+    }
+#undef SEA_TUNED
+  }
   if (vec4_ok && (fv == 0 || fv == 4)) {
     if (C <= 8) SEA_REG(8, 4);
     if (C <= 16) SEA_REG(16, 4);

@@ -41,6 +41,7 @@ _SIGS = {
     "sea_select_copy": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _vp]),
     "sea_count_ignored": (_i, [_vp, _i, _i, _i64, _vp, _vp]),
     "sea_worst_miou_greedy": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "sea_dwconv7x7": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
 }
 EXPORTS = tuple(_SIGS)
 
@@ -235,6 +236,18 @@ def select_copy(flags, x_adv, grad, x_best, grad_best, x_best_adv, pred=None, pr
                                  _p(_f32c(grad_best)), _p(_f32c(x_best_adv)), _p(pred), _p(pred_best),
                                  0 if pred is None else int_bytes(pred), B, x_adv[0].numel(),
                                  0 if pred is None else pred[0].numel(), _stream()), "sea_select_copy")
+
+
+# ------------------------------------------------------------------------------------------------ M1
+def dwconv7x7(x, weight, bias=None, flip: bool = False):
+    """Depthwise 7x7 / pad 3 / stride 1 convolution (flip=True: backward-data of the same layer)."""
+    _dev(x, weight, bias)
+    B, Cc, H, W = x.shape
+    x = _f32c(x)
+    y = torch.empty_like(x)
+    _check(lib().sea_dwconv7x7(_p(x), _p(_f32c(weight)), _p(bias), _p(y), B, Cc, H, W, int(flip), _stream()),
+           "sea_dwconv7x7")
+    return y
 
 
 # ------------------------------------------------------------------------------------------------ K9 (host)

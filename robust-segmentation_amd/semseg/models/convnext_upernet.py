@@ -6,8 +6,9 @@ and so that published checkpoints load: parameter/buffer names and shapes follow
 schema of the reference (semseg/models/uperforseg.py:382-404, backbones/convnext_orig.py:88-175;
 SURVEY Appendix B) exactly -- ``load_state_dict(strict=True)`` works both ways.
 
-The model stays on MIOpen / hipBLASLt (MFMA GEMMs and convolutions); nothing here is hand-written
-HIP.  Forward semantics mirror the reference: logits at 1/4 resolution, bilinear x4 to the input size
+The model stays on MIOpen / CK / hipBLASLt (MFMA GEMMs and convolutions) except for the depthwise
+7x7 stencil, which goes through libsea_hip (M1, include/sea_hip.h) because the library runs it ~9x
+below what an HBM-bound stencil allows.  Forward semantics mirror the reference: logits at 1/4 resolution, bilinear x4 to the input size
 (uperforseg.py:415-418), eval mode returns logits only, train mode returns (loss, logits) with the
 0.4-weighted auxiliary CE (uperforseg.py:421-439).
 """
@@ -43,7 +44,10 @@ class LayerNorm(nn.Module):
         if self.data_format == "channels_last":
             return F.layer_norm(x, (self.dim,), self.weight, self.bias, self.eps)
         y = F.layer_norm(x.permute(0, 2, 3, 1), (self.dim,), self.weight, self.bias, self.eps)
-        return y.permute(0, 3, 1, 2)
+        # materialise NCHW: a permuted view would hand channels_last-strided activations and gradients to
+        # the neighbouring stride-2 convolutions, for which MIOpen only has its naive kernel
+        # (measured: 5 convs x ~1.1 ms per dx-backward at B=8, 512x512)
+        return y.permute(0, 3, 1, 2).contiguous()
 
 
 class StochasticDepth(nn.Module):
@@ -57,6 +61,42 @@ class StochasticDepth(nn.Module):
         keep = 1.0 - self.p
         mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
         return x * mask / keep
+
+
+class _DwConv7x7(torch.autograd.Function):
+    """ConvNeXt's depthwise 7x7 through the hand-written stencil kernel (libsea_hip M1): forward and
+    input gradient.  The weight/bias gradients (only needed when training) use PyTorch."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from .. import _native as N
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return N.dwconv7x7(x.contiguous(), weight.contiguous(), bias, flip=False)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .. import _native as N
+        x, weight = ctx.saved_tensors
+        gx = gw = gb = None
+        gy = gy.contiguous()
+        if ctx.needs_input_grad[0]:
+            gx = N.dwconv7x7(gy, weight.contiguous(), None, flip=True)
+        if ctx.needs_input_grad[1]:
+            gw = torch.nn.grad.conv2d_weight(x, weight.shape, gy, padding=3, groups=x.shape[1])
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum((0, 2, 3))
+        return gx, gw, gb
+
+
+def depthwise7x7(conv: nn.Conv2d, x):
+    """Route fp32 HIP tensors through the stencil kernel, everything else through nn.Conv2d."""
+    if x.is_cuda and x.dtype == torch.float32 and conv.weight.dtype == torch.float32 and USE_HIP_DWCONV:
+        return _DwConv7x7.apply(x, conv.weight, conv.bias)
+    return conv(x)
+
+
+USE_HIP_DWCONV = True
 
 
 class ConvStem(nn.Module):
@@ -87,7 +127,7 @@ class Block(nn.Module):
         self.drop_path = StochasticDepth(drop_path) if drop_path > 0 else nn.Identity()
 
     def forward(self, x):
-        y = self.dwconv(x).permute(0, 2, 3, 1)
+        y = depthwise7x7(self.dwconv, x).permute(0, 2, 3, 1)
         y = self.pwconv2(self.act(self.pwconv1(self.norm(y))))
         if self.gamma is not None:
             y = self.gamma * y

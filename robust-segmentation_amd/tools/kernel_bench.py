@@ -85,6 +85,15 @@ def main():
                 fns[f"K2 C={C} {str(dtype)[6:]} {mname} vec{vec} u8 labels/pred +grad"] = (
                     lambda mode=mode, vec=vec: N.loss_fwd_bwd(logits, y8, w, mode, 3, 1.0 / HW, True, pred=pred8,
                                                               workspace=ws, dlogits=dl, force_vec=vec))
+        if dtype == torch.float32:
+            v0 = 4 if C <= 32 else 1
+            for tune, tname in ((1, "nt-store"), (2, "nt-load"), (3, "nt-load+store"), (4, "4 waves/SIMD"), (5, "4w+nt-store"),
+                                (7, "4w+nt-ld+st")):
+                if C > 32 and tune > 3:
+                    continue
+                fns[f"K2 C={C} float32 mask-ce-bal vec{v0} TUNE[{tname}] u8 +grad"] = (
+                    lambda tune=tune, v0=v0: N.loss_fwd_bwd(logits, y8, w, 1, 3, 1.0 / HW, True, pred=pred8, workspace=ws,
+                                                           dlogits=dl, force_vec=v0 | (tune << 4)))
         fns[f"K2 C={C} {str(dtype)[6:]} mask-ce-bal auto i64 labels/pred +grad"] = (
             lambda: N.loss_fwd_bwd(logits, y, w, 1, 3, 1.0 / HW, True, pred=pred64, workspace=ws, dlogits=dl))
         fns[f"K2 C={C} {str(dtype)[6:]} mask-ce-bal auto u8 no-grad"] = (

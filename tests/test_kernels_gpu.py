@@ -274,3 +274,40 @@ def test_counts_vs_oracle(N, C, shape, dt):
     N.class_counts(dev(conv(pred)), dev(conv(y)), C, out=out)
     assert int(out[2].sum()) == 2 * int((y >= 0).sum())
     assert torch.equal(N.count_ignored(dev(conv(y))).cpu().long(), (y == -1).view(shape[0], -1).sum(-1))
+
+
+# ------------------------------------------------------------------------------------------------ M1
+@pytest.mark.parametrize("shape", [(2, 96, 128, 128), (1, 8, 16, 16), (3, 5, 33, 47), (2, 768, 16, 16), (1, 3, 70, 9)])
+def test_dwconv7x7_forward_and_backward_data(N, shape):
+    """model-side stencil kernel vs a float64 CPU convolution (fwd incl. bias, and backward-data)"""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(shape[1])
+    B, C, H, W = shape
+    x = torch.randn(shape, generator=g)
+    w = torch.randn(C, 1, 7, 7, generator=g) * 0.1
+    b = torch.randn(C, generator=g)
+    xd = x.double().requires_grad_(True)
+    ref = F.conv2d(xd, w.double(), b.double(), padding=3, groups=C)
+    gy = torch.randn(ref.shape, generator=g)
+    (gx_ref,) = torch.autograd.grad(ref, xd, gy.double())
+    y = N.dwconv7x7(dev(x), dev(w), dev(b))
+    torch.testing.assert_close(y.cpu().double(), ref.detach(), rtol=1e-5, atol=1e-5)
+    gx = N.dwconv7x7(dev(gy), dev(w), None, flip=True)
+    torch.testing.assert_close(gx.cpu().double(), gx_ref, rtol=1e-5, atol=1e-5)
+
+
+def test_convnext_block_uses_stencil_kernel_and_matches_miopen(N):
+    from semseg.models import convnext_upernet as M
+    torch.manual_seed(0)
+    blk = M.Block(96).cuda().eval()
+    x = torch.randn(2, 96, 64, 64, device="cuda")
+    outs = []
+    for flag in (True, False):
+        M.USE_HIP_DWCONV = flag
+        xi = x.clone().requires_grad_(True)
+        y = blk(xi)
+        (gx,) = torch.autograd.grad(y, xi, torch.ones_like(y))
+        outs.append((y.detach(), gx))
+    M.USE_HIP_DWCONV = True
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-4, atol=1e-4)

@@ -45,7 +45,7 @@ def build_case(rank, B, C, backbone, device):
     return model, x, y
 
 
-def cpu_baseline(C, backbone, loss, eps, B=1, n_iter=1):
+def cpu_baseline(C, backbone, loss, eps, B=2, n_iter=3):
     """The oracle's APGD loop (the restated reference path) on the host cores, bounded sample
     (about 10-30 s): step 0 + n_iter loop iterations on B images."""
     from oracle import sea_oracle as O

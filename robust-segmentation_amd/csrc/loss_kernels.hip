@@ -550,7 +550,11 @@ static int dispatch_nchw(const LossArgs& a, bool vec4_ok, bool vec2_ok, int* vec
   } while (0)
   // force_vec: low 4 bits 0 = heuristic, 1/2/4 = pixels per lane; bits 4.. = TUNE variant (fp32 C=21/151 only)
   const int fv = a.force_vec & 15;
-  const int tune = a.force_vec >> 4;
+  int tune = a.force_vec >> 4;
+  // measured defaults (kernel_bench, MI355X): C=21 fp32 runs best with non-temporal loads+stores at 4
+  // waves/SIMD (74 % of 8 TB/s vs 65 %), C=151 with non-temporal loads (69 % vs 67.6 %)
+  if (a.force_vec == 0 && sizeof(T) == 4 && a.dlogits) tune = (C == 21 && vec4_ok) ? 7 : (C == 151 ? 2 : 0);
+  if (tune == 15) tune = 0;  // explicit "no tuning" for A/B runs
   if (tune && a.dlogits && sizeof(T) == 4) {
     dim3 block(256);
 #define SEA_TUNED(CP, V, TU)                                                                                         \

@@ -14,6 +14,8 @@ below what an HBM-bound stencil allows.  Forward semantics mirror the reference:
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -44,10 +46,8 @@ class LayerNorm(nn.Module):
         if self.data_format == "channels_last":
             return F.layer_norm(x, (self.dim,), self.weight, self.bias, self.eps)
         y = F.layer_norm(x.permute(0, 2, 3, 1), (self.dim,), self.weight, self.bias, self.eps)
-        # materialise NCHW: a permuted view would hand channels_last-strided activations and gradients to
-        # the neighbouring stride-2 convolutions, for which MIOpen only has its naive kernel
-        # (measured: 5 convs x ~1.1 ms per dx-backward at B=8, 512x512)
-        return y.permute(0, 3, 1, 2).contiguous()
+        y = y.permute(0, 3, 1, 2)
+        return y.contiguous() if LN_CONTIGUOUS else y
 
 
 class StochasticDepth(nn.Module):
@@ -97,6 +97,9 @@ def depthwise7x7(conv: nn.Conv2d, x):
 
 
 USE_HIP_DWCONV = True
+# Materialising NCHW after the channels-first LayerNorms was measured SLOWER (+8 ms per APGD step at B=8,
+# 512x512: MIOpen then picks slower NCHW algorithms for the stride-2 convolutions), so the permuted view stays.
+LN_CONTIGUOUS = os.environ.get("SEA_LN_CONTIGUOUS", "0") != "0"
 
 
 class ConvStem(nn.Module):

@@ -110,6 +110,23 @@ int sea_loss_fwd_bwd_tuned(const void* logits, int dtype, int layout, const void
                            void* workspace, size_t workspace_bytes, float* loss_sum, float* track_sum,
                            int32_t* n_correct, void* stream, int force_vec);
 
+/* K2u  K2 fused with the model's final bilinear upsample.
+ * replaces  F.interpolate(logits, size=(H,W), mode="bilinear", align_corners=False)
+ *           (semseg/models/uperforseg.py:416-418, semseg/models/segmenter.py:228) + everything K2 replaces
+ *           + the interpolate backward: the (B,C,H,W) logits and their gradient are never materialised.
+ *   low   (B,C,h,w) float32 NCHW low-resolution logits;  dlow same shape (or NULL: no gradient)
+ *   y     (B,H,W) labels; pred (B,H,W) argmax map at full resolution (or NULL)
+ *   loss_sum / track_sum / n_correct as in K2 (sums over the H*W full-resolution pixels)
+ * Any scale H/h, W/w >= 1 (ATen's align_corners=False source-index rule).  Gradients are gathered in a
+ * fixed order (no atomics): deterministic.
+ */
+size_t sea_loss_upsampled_workspace_bytes(int B, int C, int h, int w, int H, int W);
+int sea_loss_fwd_bwd_upsampled(const float* low, const void* y, int y_bytes, const float* w, int mode,
+                               int track_mode, int B, int C, int h, int wl, int H, int W, float grad_scale,
+                               float* dlow, void* pred, int pred_bytes, void* workspace,
+                               size_t workspace_bytes, float* loss_sum, float* track_sum,
+                               int32_t* n_correct, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K3  per-class integer statistics.
  * sea_class_counts replaces compute_iou_acc's loops (semseg/attacker.py:14-45), eval_performance

@@ -176,6 +176,19 @@ def loss_fwd_bwd(logits, y, weights, mode, track_mode=None, with_grad=True, igno
     return out
 
 
+def loss_fwd_bwd_upsampled(low, y, weights, mode, track_mode=None, with_grad=True, ignored_correct=True):
+    """K2u: bilinear upsample of the low-res logits to the label resolution
+    (semseg/models/uperforseg.py:416-418, segmenter.py:228) followed by everything K2 computes; the
+    gradient is returned w.r.t. the LOW-RES logits (autograd through F.interpolate)."""
+    lo = low.detach().clone().requires_grad_(with_grad)
+    hi = torch.nn.functional.interpolate(lo, size=tuple(y.shape[-2:]), mode="bilinear", align_corners=False)
+    out = loss_fwd_bwd(hi.detach(), y, weights, mode, track_mode, with_grad=with_grad, ignored_correct=ignored_correct)
+    out["logits_hi"] = hi.detach()
+    if with_grad:
+        (out["dlow"],) = torch.autograd.grad(hi, [lo], grad_outputs=out["dlogits"])
+    return out
+
+
 # --------------------------------------------------------------------------------------------------
 # K3 : per-class counts / confusion matrix
 # --------------------------------------------------------------------------------------------------

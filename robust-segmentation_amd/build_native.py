@@ -28,6 +28,7 @@ SOURCES = [
     ("linf_kernels.hip", ["-ffp-contract=off"]),
     ("apgd_control.hip", ["-ffp-contract=off"]),
     ("loss_kernels.hip", []),
+    ("loss_upsampled.hip", []),
     ("stats_kernels.hip", []),
     ("dwconv_kernels.hip", []),
     ("greedy_host.cpp", ["-ffp-contract=off"]),

@@ -34,6 +34,9 @@ _SIGS = {
                               _vp, _vp, _vp, _vp]),
     "sea_loss_fwd_bwd_tuned": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i64, _f, _vp, _vp, _i, _vp, _vp,
                                     _sz, _vp, _vp, _vp, _vp, _i]),
+    "sea_loss_upsampled_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "sea_loss_fwd_bwd_upsampled": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp, _sz, _vp,
+                                        _vp, _vp, _vp]),
     "sea_class_counts": (_i, [_vp, _i, _vp, _i, _i, _i, _i64, _i, _i, _vp, _vp, _vp, _vp]),
     "sea_confusion": (_i, [_vp, _i, _vp, _i, _i64, _i, _vp, _vp]),
     "sea_apgd_track": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -185,6 +188,38 @@ def loss_fwd_bwd(logits, y, weights, mode: int, track_mode: int, grad_scale: flo
     else:
         _check(L.sea_loss_fwd_bwd(*args), "sea_loss_fwd_bwd")
     return dict(dlogits=dlogits, loss_sum=out[0], track_sum=out[1], n_correct=out[2], pred=pred)
+
+
+def loss_fwd_bwd_upsampled(low, y, weights, mode: int, track_mode: int, grad_scale: float, want_grad: bool = True,
+                           pred=None, workspace=None, out=None, dlow=None):
+    """Run K2u on LOW-RES logits (B,C,h,w); labels / pred are at the full resolution of `y`."""
+    _dev(low, y, weights, pred)
+    low = _f32c(low)
+    B, Cc, h, w = low.shape
+    H, W = y.shape[-2:]
+    if y.shape != (B, H, W) or not y.is_contiguous():
+        raise SeaNativeError("labels must be a contiguous (B,H,W) tensor")
+    dev = low.device
+    L = lib()
+    if workspace is None:
+        nb = L.sea_loss_upsampled_workspace_bytes(B, Cc, h, w, H, W)
+        if nb == 0:
+            raise SeaNativeError("no K2u tiling for this shape")
+        workspace = torch.empty(nb, dtype=torch.uint8, device=dev)
+    if out is None:
+        out = (torch.empty(B, dtype=torch.float32, device=dev), torch.empty(B, dtype=torch.float32, device=dev),
+               torch.empty(B, dtype=torch.int32, device=dev))
+    if want_grad and dlow is None:
+        dlow = torch.empty_like(low)
+    if not want_grad:
+        dlow = None
+    if weights is not None:
+        weights = _f32c(weights)
+    _check(L.sea_loss_fwd_bwd_upsampled(_p(low), _p(y), int_bytes(y), _p(weights), mode, track_mode, B, Cc, h, w, H, W,
+                                        grad_scale, _p(dlow), _p(pred), 0 if pred is None else int_bytes(pred),
+                                        _p(workspace), workspace.numel(), _p(out[0]), _p(out[1]), _p(out[2]),
+                                        _stream()), "sea_loss_fwd_bwd_upsampled")
+    return dict(dlogits=dlow, loss_sum=out[0], track_sum=out[1], n_correct=out[2], pred=pred)
 
 
 # ------------------------------------------------------------------------------------------------ K3

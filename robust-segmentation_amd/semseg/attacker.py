@@ -209,15 +209,21 @@ def compact_labels(y: torch.Tensor, n_cls: int) -> torch.Tensor:
     return y.to(torch.int16).contiguous()
 
 
-def _forward_logits(model, x_buf, want_grad: bool):
+def _forward_logits(model, x_buf, want_grad: bool, lowres: bool = False):
+    """Model forward on a leaf alias of the iterate buffer.  With ``lowres`` the model's
+    ``forward_lowres`` hook is used: it returns the logits BEFORE the final bilinear upsample, which the
+    fused kernel K2u then interpolates on the fly."""
     x_in = x_buf.detach()
+    fn = model.forward_lowres if lowres else model
     if want_grad:
         x_in.requires_grad_(True)
         with torch.enable_grad():
-            logits = model(x_in)
+            logits = fn(x_in)
     else:
         with torch.no_grad():
-            logits = model(x_in)
+            logits = fn(x_in)
+    if lowres:
+        logits = logits[0]
     return x_in, logits
 
 
@@ -226,13 +232,24 @@ def _input_grad(logits, x_in, dlogits):
     return g if g.is_contiguous() else g.contiguous()
 
 
+FUSE_UPSAMPLE = True  # module switch: use K2u whenever the model has `forward_lowres`
+
+
 class ApgdRun:
     """One APGD run as an object: ``start()`` is step 0 (reference lines 342-383), ``step(i)`` is loop
     iteration i (lines 385-569).  ``apgd_train`` drives it; bench.py times ``step`` directly.
     Nothing in ``step`` synchronises with the host."""
 
-    def __init__(self, model, x, y, eps, n_iter, loss, track_loss, early_stop, num_classes, weights, x_start):
+    def __init__(self, model, x, y, eps, n_iter, loss, track_loss, early_stop, num_classes, weights, x_start,
+                 fuse_upsample=None):
         self.model = model
+        # fuse the model's final bilinear upsample into the loss kernel when the model offers the hook
+        if fuse_upsample is None:
+            fuse_upsample = FUSE_UPSAMPLE and hasattr(model, "forward_lowres")
+        if fuse_upsample:
+            with torch.no_grad():
+                fuse_upsample = model.forward_lowres(x[:1]) is not None
+        self.fused = bool(fuse_upsample)
         self.mode = N.MODE_BY_NAME[loss]
         self.tmode = N.MODE_BY_NAME[track_loss] if track_loss is not None else self.mode
         self.eps, self.n_iter, self.early_stop, self.num_classes = float(eps), n_iter, early_stop, num_classes
@@ -257,6 +274,7 @@ class ApgdRun:
         self.ws = N.loss_workspace(B, self.HW, device)
         self.gscale = 1.0 / float(self.HW)
         self.dlogits = None
+        self.ws_low = None
         self.last = None       # K2 outputs of the latest iterate
         self.k2_events = None  # optional list of (start, end) event pairs, one per step (bench.py)
 
@@ -265,9 +283,18 @@ class ApgdRun:
         if self.k2_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        r = N.loss_fwd_bwd(logits.detach(), self.yc, self.w, self.mode, self.tmode, self.gscale, want_grad=want_grad,
-                           pred=self.pred, workspace=self.ws, out=self.stats,
-                           dlogits=self.dlogits if want_grad else None)
+        if self.fused:
+            if self.ws_low is None:
+                self.ws_low = torch.empty(N.lib().sea_loss_upsampled_workspace_bytes(
+                    self.B, logits.shape[1], logits.shape[2], logits.shape[3], self.x.shape[-2], self.x.shape[-1]),
+                    dtype=torch.uint8, device=logits.device)
+            r = N.loss_fwd_bwd_upsampled(logits.detach().contiguous(), self.yc, self.w, self.mode, self.tmode,
+                                         self.gscale, want_grad=want_grad, pred=self.pred, workspace=self.ws_low,
+                                         out=self.stats, dlow=self.dlogits if want_grad else None)
+        else:
+            r = N.loss_fwd_bwd(logits.detach(), self.yc, self.w, self.mode, self.tmode, self.gscale,
+                               want_grad=want_grad, pred=self.pred, workspace=self.ws, out=self.stats,
+                               dlogits=self.dlogits if want_grad else None)
         if ev is not None:
             ev[1].record()
             self.k2_events.append(ev)
@@ -277,7 +304,7 @@ class ApgdRun:
         return r
 
     def start(self):
-        x_in, logits = _forward_logits(self.model, self.x_adv, True)
+        x_in, logits = _forward_logits(self.model, self.x_adv, True, self.fused)
         r = self._loss(logits, True)
         self.grad = _input_grad(logits, x_in, r["dlogits"])
         del logits
@@ -296,7 +323,7 @@ class ApgdRun:
         self.x_old, self.x_adv, self.x_next = self.x_adv, self.x_next, self.x_old
         # ---- model forward, fused loss/grad/track/acc/argmax (K2), model input-gradient
         want = i < self.n_iter - 1  # the reference skips the last backward (line 467)
-        x_in, logits = _forward_logits(self.model, self.x_adv, want)
+        x_in, logits = _forward_logits(self.model, self.x_adv, want, self.fused)
         r = self._loss(logits, want)
         if want:
             self.grad = _input_grad(logits, x_in, r["dlogits"])

@@ -279,6 +279,11 @@ class UperNetForSemanticSegmentation(nn.Module):
             self.decode_head.init_weights()
             self.auxiliary_head.init_weights()
 
+    def forward_lowres(self, input):
+        """(logits at 1/4 resolution, output size): semseg.attacker fuses the final bilinear upsample
+        into its loss kernel (K2u) when a model offers this hook."""
+        return self.decode_head(self.backbone(input)), tuple(input.shape[2:])
+
     def forward(self, input, lbl=None):
         feats = self.backbone(input)
         logits = _up(self.decode_head(feats), input.shape[2:])

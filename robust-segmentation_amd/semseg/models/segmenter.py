@@ -205,6 +205,16 @@ class SegMenter(nn.Module):
     def no_weight_decay(self):
         return {"encoder." + k for k in self.encoder.no_weight_decay()} | {"decoder." + k for k in self.decoder.no_weight_decay()}
 
+    def forward_lowres(self, im):
+        """(masks at 1/16 resolution, output size) when no padding is involved, else None (see
+        UperNetForSemanticSegmentation.forward_lowres)."""
+        H0, W0 = im.shape[2:]
+        if H0 % self.patch_size or W0 % self.patch_size:
+            return None
+        x = self.encoder(im, pre_neck=True)
+        x = x[:, 0 if "SAM" in self.backbone else 1 + int(self.encoder.distilled):]
+        return self.decoder(x, (H0, W0)).contiguous(), (H0, W0)
+
     def forward(self, im):
         H0, W0 = im.shape[2:]
         ph, pw = (-H0) % self.patch_size, (-W0) % self.patch_size

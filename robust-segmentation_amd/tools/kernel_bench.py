@@ -111,6 +111,32 @@ def main():
                 report(k, ms, B * HW * (2 * C * s + 16))
         del logits, dl
 
+    # ---------------- K2u (fused bilinear upsample + loss) vs upsample + K2 + upsample-backward --------------
+    for C, hl, lab in ((21, 128, "UperNet x4"), (151, 128, "UperNet x4"), (151, 32, "Segmenter x16")):
+        low = torch.randn(B, C, hl, hl, device="cuda") * 3
+        y8 = torch.nn.functional.interpolate(low, size=(H, W), mode="bilinear").max(1)[1].to(torch.uint8)
+        w = torch.rand(C, device="cuda")
+        dlow = torch.empty_like(low)
+        pred8 = torch.empty(B, H, W, dtype=torch.uint8, device="cuda")
+        hi = torch.empty(B, C, H, W, device="cuda")
+        dl = torch.empty_like(hi)
+        ws = N.loss_workspace(B, HW, "cuda")
+
+        def unfused():
+            lo = low.detach().requires_grad_(True)
+            up = torch.nn.functional.interpolate(lo, size=(H, W), mode="bilinear", align_corners=False)
+            r = N.loss_fwd_bwd(up.detach(), y8, w, 1, 3, 1.0 / HW, True, pred=pred8, workspace=ws, dlogits=dl)
+            return torch.autograd.grad(up, lo, r["dlogits"])
+
+        t = timeit({
+            f"K2u fused C={C} {lab} +grad": lambda: N.loss_fwd_bwd_upsampled(low, y8, w, 1, 3, 1.0 / HW, True, pred=pred8, dlow=dlow),
+            f"K2u fused C={C} {lab} no-grad": lambda: N.loss_fwd_bwd_upsampled(low, y8, w, 1, 3, 1.0 / HW, False, pred=pred8),
+            f"ATen upsample + K2 + upsample-bwd C={C} {lab}": unfused,
+        }, rounds=7)
+        for k, ms in t.items():
+            report(k, ms, B * HW * ((1 if "no-grad" in k else 2) * C * 4 + 16))
+        del low, hi, dl, dlow
+
     # ---------------- K1 / K6 / K5 / K4 -------------------------------------------------------------
     g = torch.Generator(device="cuda").manual_seed(1)
     x = torch.rand(B, 3, H, W, generator=g, device="cuda")

@@ -311,3 +311,78 @@ def test_convnext_block_uses_stencil_kernel_and_matches_miopen(N):
     M.USE_HIP_DWCONV = True
     torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ K2u
+@pytest.mark.parametrize("case", [
+    (2, 21, 16, 16, 64, 64),      # x4, UperNet-like
+    (2, 5, 8, 8, 128, 128),       # x16, Segmenter-like
+    (1, 21, 30, 30, 119, 119),    # non-integer scale (473x473 crops give 119 -> 473)
+    (2, 151, 12, 20, 48, 80),     # many classes, non-square
+    (1, 3, 7, 5, 7, 5),           # scale 1
+    (3, 21, 13, 11, 50, 45),      # ragged tiles + non-integer scales
+])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_fused_upsample_loss_kernel(N, case, mode):
+    B, C, h, w, H, W = case
+    g = torch.Generator().manual_seed(h * 1000 + H + mode)
+    low = torch.randn(B, C, h, w, generator=g) * 3
+    hi_ref = torch.nn.functional.interpolate(low, size=(H, W), mode="bilinear", align_corners=False)
+    y = hi_ref.max(1)[1]
+    flip = torch.rand(B, H, W, generator=g) < 0.3
+    y[flip] = torch.randint(0, C, (int(flip.sum()),), generator=g)
+    y[torch.rand(B, H, W, generator=g) < 0.05] = -1
+    wts = torch.rand(C, generator=g) + 0.01
+    ref = O.loss_fwd_bwd_upsampled(low, y, wts, mode, 3, with_grad=True)
+    pred = torch.empty(B, H, W, dtype=torch.int64, device="cuda")
+    r = N.loss_fwd_bwd_upsampled(dev(low), dev(y), dev(wts), mode, 3, 1.0 / (H * W), want_grad=True, pred=pred)
+    torch.cuda.synchronize()
+    # argmax / counts: exact wherever the top-2 margin of the interpolated logits exceeds float noise
+    top2 = ref["logits_hi"].topk(2, dim=1)[0]
+    safe = (top2[:, 0] - top2[:, 1]) > 1e-4
+    assert torch.equal(pred.cpu()[safe], ref["pred"][safe])
+    n_unsafe = (~safe).view(B, -1).sum(-1)
+    assert ((r["n_correct"].cpu().long() - ref["n_correct"]).abs() <= n_unsafe).all()
+    if int(n_unsafe.sum()) == 0:
+        assert torch.equal(r["n_correct"].cpu().long(), ref["n_correct"])
+    torch.testing.assert_close((r["loss_sum"] / (H * W)).cpu(), ref["loss_img"], rtol=1e-4, atol=LOSS_ATOL)
+    torch.testing.assert_close((r["track_sum"] / (H * W)).cpu(), ref["track_img"], rtol=1e-4, atol=LOSS_ATOL)
+    scale = ref["dlow"].abs().max().item()
+    torch.testing.assert_close(r["dlogits"].cpu(), ref["dlow"], rtol=2e-3, atol=2e-4 * scale + 1e-9)
+    # determinism (gather formulation, no atomics)
+    r2 = N.loss_fwd_bwd_upsampled(dev(low), dev(y), dev(wts), mode, 3, 1.0 / (H * W), want_grad=True)
+    assert torch.equal(r["dlogits"], r2["dlogits"]) and torch.equal(r["loss_sum"], r2["loss_sum"])
+
+
+def test_fused_and_unfused_attack_agree(N):
+    """ApgdRun with K2u (low-res logits + fused upsample) vs K2 on the upsampled logits, same model"""
+    from semseg import attacker as A
+
+    class LowResNet(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(3)
+            self.c = torch.nn.Conv2d(3, 7, 3, stride=4, padding=1)
+
+        def forward_lowres(self, x):
+            return 4.0 * self.c(x), tuple(x.shape[2:])
+
+        def forward(self, x):
+            low, size = self.forward_lowres(x)
+            return torch.nn.functional.interpolate(low, size=size, mode="bilinear", align_corners=False)
+
+    net = LowResNet().cuda().eval()
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(2, 3, 64, 64, generator=g).cuda()
+    with torch.no_grad():
+        y = net(x).max(1)[1]
+    outs = []
+    for fuse in (True, False):
+        A.FUSE_UPSAMPLE = fuse
+        outs.append(A.apgd_train(net, x, y, "Linf", 8 / 255, n_iter=8, loss="mask-ce-avg", track_loss="ce-avg",
+                                 num_classes=7))
+    A.FUSE_UPSAMPLE = True
+    (xb, acc, lb, xba), (xb2, acc2, lb2, xba2) = outs
+    assert (acc - acc2).abs().max() <= 3.0 / 4096
+    torch.testing.assert_close(lb, lb2, rtol=1e-3, atol=1e-4)
+    assert ((xba - xba2).abs() > 1e-6).float().mean() < 0.03

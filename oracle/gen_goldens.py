@@ -268,5 +268,54 @@ def main():
             unions=st["run_union_imwise"])
 
 
+def config1():
+    """BASELINE.json configs[0]: UperNet-ConvNeXt-T, 2 synthetic 512x512 images, 5-step Mask-CE APGD
+    (apgd_largereps, eps=4/255) on CPU through the REAL reference.  Weights: the build's model seeded with
+    torch.manual_seed(0), copied into the reference's model (identical state-dict schema)."""
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    sys.path.insert(0, os.path.join(ROOT, "robust-segmentation_amd"))
+    from semseg.models.convnext_upernet import UperNetForSemanticSegmentation as Mine
+    torch.manual_seed(0)
+    sd = Mine("ConvNeXt-T_CVST", 21, None).state_dict()
+    for k in [k for k in sys.modules if k == "semseg" or k.startswith("semseg.")]:
+        del sys.modules[k]
+    sys.path.remove(os.path.join(ROOT, "robust-segmentation_amd"))
+    os.chdir(REF)
+    import semseg.attacker as A
+    from semseg.models.uperforseg import UperNetForSemanticSegmentation as Ref
+    from semseg.utils.utils import VOC_WTS
+    ref = Ref("ConvNeXt-T_CVST", 21, None).eval()
+    ref.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.rand(2, 3, 512, 512, generator=g)
+    with torch.no_grad():
+        y = ref(x).max(1)[1]
+    w = torch.tensor(VOC_WTS)
+    import contextlib
+    import io
+    import time
+    out = dict(y=y.to(torch.uint8))
+    for loss in ("mask-ce-avg",):
+        torch.manual_seed(4321)
+        t0 = time.time()
+        with contextlib.redirect_stdout(io.StringIO()):
+            xa, _, acc = A.apgd_largereps(ref, x.clone(), y, w, norm="Linf", eps=4.0 / 255, n_iter=5, n_restarts=1,
+                                          use_rs=True, loss=loss, verbose=False, track_loss="ce-avg", log_path=None,
+                                          num_classes=21, early_stop=True)
+        dt = time.time() - t0
+        with torch.no_grad():
+            pa = ref(xa).max(1)[1]
+        m_acc, a_acc, m_iou = A.compute_iou_acc(pa.clone(), y, 21)
+        idx = torch.randperm(xa.numel(), generator=torch.Generator().manual_seed(5))[:4096]
+        out.update(acc=acc, idx=idx, x_adv_samples=xa.flatten()[idx], adv_aacc=a_acc, adv_miou=m_iou,
+                   adv_macc=m_acc, seconds=np.float64(dt), linf=(xa - x).abs().max())
+        print(loss, "acc", acc.tolist(), "aAcc", float(a_acc), "mIoU", float(m_iou), f"{dt:.1f}s")
+    npz("g8_config1_upernet_t", **out)
+
+
 if __name__ == "__main__":
-    main()
+    if "--config1" in sys.argv:
+        config1()
+    else:
+        main()

@@ -78,7 +78,8 @@ __device__ __forceinline__ float loss_value_u(int mode, bool valid, bool correct
 //   lowt  [C][TLP][TLP]      low-res tile incl. 1-pixel halo, TLP = TL + 2
 //   rmap  [RMAX] x {i0,i1 (local), lam}  row / column interpolation tables of the full-res region
 //   pm, pA, pK [RMAX*RMAX], plab int [RMAX*RMAX]   per full-res pixel softmax statistics
-//   rng   int [4][TL]        per low-res row/col: first/last region index with non-zero weight
+//   rbeg, cbeg int [TL+3]   first region row/col whose source cell index i0 is >= ya-1+t (cell t = rows
+//                           [rbeg[t], rbeg[t+1]))
 template <bool GRAD>
 __global__ __launch_bounds__(256) void loss_upsampled_kernel(
     const float* __restrict__ low, const void* __restrict__ y, int y_bytes, const float* __restrict__ w, int mode,
@@ -97,7 +98,8 @@ __global__ __launch_bounds__(256) void loss_upsampled_kernel(
   float* pA = pm + RMAX * RMAX;
   float* pK = pA + RMAX * RMAX;
   int* plab = (int*)(pK + RMAX * RMAX);
-  int* rng = plab + RMAX * RMAX;                        // [4][TL]: row_lo,row_hi,col_lo,col_hi
+  int* rbeg = plab + RMAX * RMAX;                       // TL+3
+  int* cbeg = rbeg + (TL + 3);                          // TL+3
 
   const int b = blockIdx.z;
   const int ya = blockIdx.y * TL, xa = blockIdx.x * TL;             // owned low-res tile origin
@@ -131,13 +133,10 @@ __global__ __launch_bounds__(256) void loss_upsampled_kernel(
     c_i1[i] = m.i1 - (xa - 1);
     c_lam[i] = m.lam;
   }
-  if (threadIdx.x < TL) {
-    // region rows that touch low-res row ya+t: i0 in {ya+t-1, ya+t}
-    const int t = threadIdx.x;
-    rng[0 * TL + t] = first_dst_with_i0_ge(ya + t - 1, rh, h, H) - Y0e;
-    rng[1 * TL + t] = min(first_dst_with_i0_ge(ya + t + 1, rh, h, H), Y1) - Y0e;
-    rng[2 * TL + t] = first_dst_with_i0_ge(xa + t - 1, rw, wl, W) - X0e;
-    rng[3 * TL + t] = min(first_dst_with_i0_ge(xa + t + 1, rw, wl, W), X1) - X0e;
+  if (threadIdx.x < TL + 3) {
+    const int t = threadIdx.x;  // local cell index: global source index ya-1+t
+    rbeg[t] = min(max(first_dst_with_i0_ge(ya - 1 + t, rh, h, H), Y0e), Y1) - Y0e;
+    cbeg[t] = min(max(first_dst_with_i0_ge(xa - 1 + t, rw, wl, W), X0e), X1) - X0e;
   }
   __syncthreads();
 
@@ -151,24 +150,27 @@ __global__ __launch_bounds__(256) void loss_upsampled_kernel(
     const bool owned = (Y >= Y0o) && (X >= X0o);
     int lab = load_label_rt(y, y_bytes, ((int64_t)b * H + Y) * W + X);
     lab = (lab < 0 || lab >= C) ? -1 : lab;
-    const int o00 = r_i0[ri] * TLP + c_i0[ci], o01 = r_i0[ri] * TLP + c_i1[ci];
-    const int o10 = r_i1[ri] * TLP + c_i0[ci], o11 = r_i1[ri] * TLP + c_i1[ci];
+    // ONE pass over the classes with an online soft-max (running max + rescaled sum), and the two
+    // horizontally adjacent corner values fetched as a pair (ds_read2_b32): 2 LDS instructions per class
+    // instead of 8.  The tile rows are TLP wide, so index+1 is always inside the row buffer.
+    const int o0 = r_i0[ri] * TLP + c_i0[ci], o1 = r_i1[ri] * TLP + c_i0[ci];
+    const bool same_col = (c_i1[ci] == c_i0[ci]);
     const float ly = r_lam[ri], lx = c_lam[ci];
-    float m = -INFINITY, zy = 0.f;
+    float m = -INFINITY, zy = 0.f, s = 0.f;
     int arg = 0;
     for (int c = 0; c < C; ++c) {
       const float* t = lowt + c * P2;
-      const float z = lerp2(t[o00], t[o01], t[o10], t[o11], lx, ly);
-      if (z > m) {  // strict: first maximum wins
+      const float a0 = t[o0], a1 = t[o0 + 1], b0 = t[o1], b1 = t[o1 + 1];
+      const float z = lerp2(a0, same_col ? a0 : a1, b0, same_col ? b0 : b1, lx, ly);
+      zy = (lab == c) ? z : zy;
+      const float e = __expf(-fabsf(z - m));  // exp(-inf) = 0 on the first class
+      if (z > m) {                              // strict: first maximum wins
+        s = s * e + 1.f;
         m = z;
         arg = c;
+      } else {
+        s += e;
       }
-      zy = (lab == c) ? z : zy;
-    }
-    float s = 0.f;
-    for (int c = 0; c < C; ++c) {
-      const float* t = lowt + c * P2;
-      s += __expf(lerp2(t[o00], t[o01], t[o10], t[o11], lx, ly) - m);
     }
     const bool valid = lab >= 0;
     const bool correct = valid && (arg == lab);
@@ -201,39 +203,69 @@ __global__ __launch_bounds__(256) void loss_upsampled_kernel(
   }
 
   // ---- phase B: gather the gradient of every owned (low-res pixel, class) ---------------------------
+  // A thread owns one low-res pixel and a chunk of CK classes.  The full-res pixels that touch the
+  // low-res pixel (yl,xl) live in the four source cells (yl-1|yl) x (xl-1|xl); inside one cell all pixels
+  // interpolate between the same four low-res values, which therefore sit in registers (per class) while
+  // the per-pixel softmax statistics (max, K/sum, K, label) are read once and reused for the whole chunk.
   if (GRAD) {
     __syncthreads();
+    constexpr int CK = 8;
     const int nlx = xb - xa, nly = yb - ya;
+    const int nchunk = (C + CK - 1) / CK;
     float* dlb = dlow + (int64_t)b * C * h * wl;
-    for (int item = threadIdx.x; item < C * nly * nlx; item += 256) {
-      const int c = item / (nly * nlx), rem = item - c * nly * nlx;
+    for (int item = threadIdx.x; item < nchunk * nly * nlx; item += 256) {
+      const int ck = item / (nly * nlx), rem = item - ck * nly * nlx;
       const int ty = rem / nlx, tx = rem - ty * nlx;
-      const int yl = ty + 1, xl = tx + 1;                  // local low-res coordinates inside lowt
-      const float* t = lowt + c * P2;
-      float acc = 0.f;
-      const int i_lo = rng[0 * TL + ty], i_hi = rng[1 * TL + ty];
-      const int j_lo = rng[2 * TL + tx], j_hi = rng[3 * TL + tx];
-      for (int ri = i_lo; ri < i_hi; ++ri) {
-        const float ly = r_lam[ri];
-        const int a0 = r_i0[ri], a1 = r_i1[ri];
-        const float wyv = ((a0 == yl) ? (1.f - ly) : 0.f) + ((a1 == yl) ? ly : 0.f);
-        if (wyv == 0.f) continue;
-        float rowacc = 0.f;
-        for (int ci = j_lo; ci < j_hi; ++ci) {
-          const float lx = c_lam[ci];
-          const int b0 = c_i0[ci], b1 = c_i1[ci];
-          const float wxv = ((b0 == xl) ? (1.f - lx) : 0.f) + ((b1 == xl) ? lx : 0.f);
-          const int p = ri * RW + ci;
-          const float kk = pK[p];
-          if (wxv == 0.f || kk == 0.f) continue;
-          const float z = lerp2(t[a0 * TLP + b0], t[a0 * TLP + b1], t[a1 * TLP + b0], t[a1 * TLP + b1], lx, ly);
-          float g = pA[p] * __expf(z - pm[p]);
-          g = (plab[p] == c) ? g - kk : g;
-          rowacc += wxv * g;
+      const int yl = ty + 1, xl = tx + 1;  // local low-res coordinates inside lowt
+      const int c0 = ck * CK;
+      float acc[CK];
+#pragma unroll
+      for (int k = 0; k < CK; ++k) acc[k] = 0.f;
+      for (int qy = 0; qy < 2; ++qy) {
+        const int cy = yl - 1 + qy;                       // source cell row (local)
+        const int i_lo = rbeg[cy], i_hi = rbeg[cy + 1];
+        if (i_lo >= i_hi) continue;
+        const int cy1 = r_i1[i_lo];                       // constant inside the cell
+        for (int qx = 0; qx < 2; ++qx) {
+          const int cx = xl - 1 + qx;
+          const int j_lo = cbeg[cx], j_hi = cbeg[cx + 1];
+          if (j_lo >= j_hi) continue;
+          const int cx1 = c_i1[j_lo];
+          float v00[CK], v01[CK], v10[CK], v11[CK];
+#pragma unroll
+          for (int k = 0; k < CK; ++k) {
+            const int c = min(c0 + k, C - 1);
+            const float* t = lowt + c * P2;
+            v00[k] = t[cy * TLP + cx];
+            v01[k] = t[cy * TLP + cx1];
+            v10[k] = t[cy1 * TLP + cx];
+            v11[k] = t[cy1 * TLP + cx1];
+          }
+          for (int ri = i_lo; ri < i_hi; ++ri) {
+            const float ly = r_lam[ri];
+            const float wyv = ((cy == yl) ? (1.f - ly) : 0.f) + ((cy1 == yl) ? ly : 0.f);
+            if (wyv == 0.f) continue;
+            for (int ci = j_lo; ci < j_hi; ++ci) {
+              const float lx = c_lam[ci];
+              const float wv = wyv * (((cx == xl) ? (1.f - lx) : 0.f) + ((cx1 == xl) ? lx : 0.f));
+              const int p = ri * RW + ci;
+              const float kk = pK[p];
+              if (wv == 0.f || kk == 0.f) continue;
+              const float mm = pm[p], wa = wv * pA[p], wk = wv * kk;
+              const int lb = plab[p] - c0;
+#pragma unroll
+              for (int k = 0; k < CK; ++k) {
+                const float z = lerp2(v00[k], v01[k], v10[k], v11[k], lx, ly);
+                acc[k] = fmaf(wa, __expf(z - mm), acc[k]);
+                acc[k] -= (lb == k) ? wk : 0.f;
+              }
+            }
+          }
         }
-        acc += wyv * rowacc;
       }
-      dlb[((int64_t)c * h + (ya + ty)) * wl + (xa + tx)] = acc;
+#pragma unroll
+      for (int k = 0; k < CK; ++k)
+        if (c0 + k < C) dlb[((int64_t)(c0 + k) * h + (ya + ty)) * wl + (xa + tx)] = acc[k];
     }
   }
 
@@ -305,7 +337,7 @@ static bool plan_upsampled(int C, int h, int wl, int H, int W, UpsPlan* out) {
   for (int TL = 8; TL >= 1; --TL) {
     const int RMAX = (int)((TL + 1) * s) + 4;
     const size_t TLP = TL + 2;
-    const size_t lds = sizeof(float) * ((size_t)C * TLP * TLP + 6 * (size_t)RMAX + 4 * (size_t)RMAX * RMAX + 4 * (size_t)TL);
+    const size_t lds = sizeof(float) * ((size_t)C * TLP * TLP + 6 * (size_t)RMAX + 4 * (size_t)RMAX * RMAX + 2 * (size_t)(TL + 3));
     if (lds <= 96 * 1024 && RMAX <= 72) {
       out->TL = TL;
       out->RMAX = RMAX;

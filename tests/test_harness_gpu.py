@@ -46,3 +46,28 @@ def test_infer_synthetic_end_to_end(tmp_path):
     saved = torch.load(os.path.join(str(tmp_path), f"worse_SEA_UperNet_ConvNeXt-T_CVST_pascalvoc_8.0.pt"))
     assert set(saved) == {"seed", "worst_Acc", "worst_Acc_indiv", "final_miou", "loss-wise_miou"}
     assert os.path.exists(os.path.join(str(tmp_path), "sea-stats", "loss_wise_UperNet_ConvNeXt-T_CVST_js-avg_N_8.0.txt"))
+
+
+def test_pirat_training_step_runs_and_keeps_param_grads_clean(tmp_path):
+    """inner PGD must not leave anything in .grad (the reference's loss.backward() does) and the
+    outer step must train"""
+    import yaml
+    from tools import train_rob_seg
+    from semseg.models import UperNetForSemanticSegmentation
+    from semseg.val import Pgd_Attack_1
+    model = UperNetForSemanticSegmentation("ConvNeXt-T_CVST", 21, None).cuda().eval()
+    x = torch.rand(2, 3, 64, 64, device="cuda")
+    y = torch.randint(0, 21, (2, 64, 64), device="cuda")
+    x_adv, logits, _ = Pgd_Attack_1(epsilon=4 / 255, alpha=1e-2, num_iter=3, los="pgd").adv_attack(model, x, y)
+    assert all(p.grad is None for p in model.parameters())
+    assert (x_adv - x).abs().max() <= 4 / 255 + 1e-6 and x_adv.min() >= 0 and x_adv.max() <= 1
+    cfg = yaml.safe_load(open(os.path.join(PKG, "configs", "pascalvoc_convnext.yaml")))
+    cfg["TRAIN"]["IMAGE_SIZE"] = [64, 64]
+    cfg["TRAIN"]["N_ITERS"] = 2
+    cfg_path = str(tmp_path / "cfg.yaml")
+    yaml.safe_dump(cfg, open(cfg_path, "w"))
+    out = str(tmp_path / "train.json")
+    train_rob_seg.main(["--cfg", cfg_path, "--synthetic", "8", "--steps", "3", "--warmup", "1", "--batch_size", "2",
+                        "--json", out])
+    s = json.load(open(out))
+    assert s["inner_pgd_steps"] == 2 and s["samples_per_s"] > 0 and s["last_loss"] == s["last_loss"]

@@ -204,6 +204,17 @@ int sea_worst_miou_greedy(const float* ints, const float* unions, int A, int N, 
 int sea_dwconv7x7(const float* x, const float* w, const float* bias, float* y, int B, int C, int H,
                   int W, int flip, void* stream);
 
+/* M2  (model side) bilinear up-sampling, align_corners=False, fp32 NCHW planes: forward and its
+ * backward w.r.t. the input (gather formulation, deterministic; ATen scatters with atomics).
+ * Replaces F.interpolate(..., mode="bilinear") in UperNet's FPN / PSP / final logits
+ * (semseg/models/uperforseg.py:171-177, 236-262, 416-418) where ATen reaches ~0.3 TB/s.
+ *   x / gx: (planes, h, w);  y / gy: (planes, H, W);  H >= h, W >= w, any (non-integer) scale.
+ */
+int sea_upsample_bilinear_fwd(const float* x, float* y, int64_t planes, int h, int w, int H, int W,
+                              void* stream);
+int sea_upsample_bilinear_bwd(const float* gy, float* gx, int64_t planes, int h, int w, int H, int W,
+                              void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,7 @@ SOURCES = [
     ("loss_upsampled.hip", []),
     ("stats_kernels.hip", []),
     ("dwconv_kernels.hip", []),
+    ("upsample_kernels.hip", []),
     ("greedy_host.cpp", ["-ffp-contract=off"]),
     ("api_misc.cpp", []),
 ]

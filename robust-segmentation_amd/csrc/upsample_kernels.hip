@@ -1,0 +1,198 @@
+// M2 (model side): bilinear up-sampling, align_corners=False, fp32 NCHW planes - forward and backward.
+//
+// UperNet's FPN up-samples 512-channel maps three times per forward (and again top-down), plus the final
+// logits (semseg/models/uperforseg.py:236-262, 416-418).  ATen's upsample_bilinear2d kernels run these at
+// ~0.3 TB/s (0.9 ms for a 268 MB output; ~8 % of an APGD step forward+backward) although the op is a pure
+// HBM stream: write the output once (forward) / read the output gradient once (backward).
+//
+// Forward: one lane writes 4 consecutive output pixels (float4 store); its <= 2x5 input values come from
+// L1/L2 (the input is s^2 times smaller than the output).
+// Backward: gather, deterministic (ATen scatters with atomicAdd): a workgroup owns a TIxTI tile of INPUT
+// pixels of one plane, stages the output-gradient region that touches it in LDS with coalesced row
+// reads, and every input pixel sums its footprint in a fixed order, cell by cell (same bookkeeping as
+// loss_upsampled.hip).
+// Source-index rule = ATen: src = r*(dst+0.5)-0.5 clamped at 0, i0=floor(src), i1=min(i0+1,n-1).
+#include "sea_common.h"
+
+namespace sea {
+
+struct AxisMapU {
+  int i0, i1;
+  float lam;
+};
+
+__device__ __forceinline__ AxisMapU axis_map_u(int dst, float r, int n_in) {
+  float src = r * ((float)dst + 0.5f) - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  AxisMapU m;
+  m.i0 = (int)src;
+  if (m.i0 > n_in - 1) m.i0 = n_in - 1;
+  m.i1 = m.i0 + ((m.i0 < n_in - 1) ? 1 : 0);
+  m.lam = src - (float)m.i0;
+  return m;
+}
+
+__device__ __forceinline__ int first_dst_ge(int t, float r, int n_in, int n_out) {
+  if (t <= 0) return 0;
+  if (t > n_in - 1) return n_out;
+  int d = (int)ceilf(((float)t + 0.5f) / r - 0.5f);
+  d = d < 0 ? 0 : (d > n_out ? n_out : d);
+  while (d > 0 && axis_map_u(d - 1, r, n_in).i0 >= t) --d;
+  while (d < n_out && axis_map_u(d, r, n_in).i0 < t) ++d;
+  return d;
+}
+
+// grid = (ceil(W/64), ceil(H/16), planes); block 256 = 16 rows x 16 strips of 4 pixels
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int h,
+                                                           int w, int H, int W, float rh, float rw) {
+  const int plane = blockIdx.z;
+  const int Y = blockIdx.y * 16 + (threadIdx.x >> 4);
+  const int X0 = (blockIdx.x * 16 + (threadIdx.x & 15)) * 4;
+  if (Y >= H || X0 >= W) return;
+  const float* xp = x + (int64_t)plane * h * w;
+  const AxisMapU my = axis_map_u(Y, rh, h);
+  const float* r0 = xp + (int64_t)my.i0 * w;
+  const float* r1 = xp + (int64_t)my.i1 * w;
+  float out[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int X = min(X0 + j, W - 1);
+    const AxisMapU mx = axis_map_u(X, rw, w);
+    const float top = (1.f - mx.lam) * r0[mx.i0] + mx.lam * r0[mx.i1];
+    const float bot = (1.f - mx.lam) * r1[mx.i0] + mx.lam * r1[mx.i1];
+    out[j] = (1.f - my.lam) * top + my.lam * bot;
+  }
+  float* yp = y + ((int64_t)plane * H + Y) * W + X0;
+  if (X0 + 3 < W && ((((uintptr_t)yp) & 15) == 0)) {
+    *reinterpret_cast<float4*>(yp) = make_float4(out[0], out[1], out[2], out[3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (X0 + j < W) yp[j] = out[j];
+  }
+}
+
+// grid = (tiles_x, tiles_y, planes); dynamic LDS: go region [RMAX][RLD] + axis tables + cell tables
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int h,
+                                                           int w, int H, int W, float rh, float rw, int TI, int RMAX) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int RLD = RMAX + 1;
+  float* reg = smem;                         // RMAX * RLD
+  int* r_i1 = (int*)(reg + RMAX * RLD);      // RMAX (local index of the bottom source row)
+  float* r_lam = (float*)(r_i1 + RMAX);
+  int* c_i1 = (int*)(r_lam + RMAX);
+  float* c_lam = (float*)(c_i1 + RMAX);
+  int* rbeg = (int*)(c_lam + RMAX);          // TI + 3
+  int* cbeg = rbeg + (TI + 3);
+  const int plane = blockIdx.z;
+  const int ya = blockIdx.y * TI, xa = blockIdx.x * TI;
+  const int yb = min(ya + TI, h), xb = min(xa + TI, w);
+  const int Y0 = first_dst_ge(ya - 1, rh, h, H), Y1 = first_dst_ge(yb, rh, h, H);
+  const int X0 = first_dst_ge(xa - 1, rw, w, W), X1 = first_dst_ge(xb, rw, w, W);
+  const int RH = Y1 - Y0, RW = X1 - X0;
+  const float* gp = gy + (int64_t)plane * H * W;
+  for (int i = threadIdx.x; i < RH * RW; i += 256) {
+    const int ri = i / RW, ci = i - ri * RW;
+    reg[ri * RLD + ci] = gp[(int64_t)(Y0 + ri) * W + X0 + ci];
+  }
+  for (int i = threadIdx.x; i < RH; i += 256) {
+    const AxisMapU m = axis_map_u(Y0 + i, rh, h);
+    r_i1[i] = m.i1 - (ya - 1);
+    r_lam[i] = m.lam;
+  }
+  for (int i = threadIdx.x; i < RW; i += 256) {
+    const AxisMapU m = axis_map_u(X0 + i, rw, w);
+    c_i1[i] = m.i1 - (xa - 1);
+    c_lam[i] = m.lam;
+  }
+  if (threadIdx.x < TI + 3) {
+    const int t = threadIdx.x;
+    rbeg[t] = min(max(first_dst_ge(ya - 1 + t, rh, h, H), Y0), Y1) - Y0;
+    cbeg[t] = min(max(first_dst_ge(xa - 1 + t, rw, w, W), X0), X1) - X0;
+  }
+  __syncthreads();
+  const int nly = yb - ya, nlx = xb - xa;
+  float* op = gx + (int64_t)plane * h * w;
+  for (int item = threadIdx.x; item < nly * nlx; item += 256) {
+    const int ty = item / nlx, tx = item - ty * nlx;
+    const int yl = ty + 1, xl = tx + 1;
+    float acc = 0.f;
+    for (int qy = 0; qy < 2; ++qy) {
+      const int cy = yl - 1 + qy;
+      const int i_lo = rbeg[cy], i_hi = rbeg[cy + 1];
+      if (i_lo >= i_hi) continue;
+      const int cy1 = r_i1[i_lo];
+      for (int ri = i_lo; ri < i_hi; ++ri) {
+        const float ly = r_lam[ri];
+        const float wy = ((cy == yl) ? (1.f - ly) : 0.f) + ((cy1 == yl) ? ly : 0.f);
+        if (wy == 0.f) continue;
+        float rowacc = 0.f;
+        for (int qx = 0; qx < 2; ++qx) {
+          const int cx = xl - 1 + qx;
+          const int j_lo = cbeg[cx], j_hi = cbeg[cx + 1];
+          if (j_lo >= j_hi) continue;
+          const int cx1 = c_i1[j_lo];
+          for (int ci = j_lo; ci < j_hi; ++ci) {
+            const float lx = c_lam[ci];
+            const float wx = ((cx == xl) ? (1.f - lx) : 0.f) + ((cx1 == xl) ? lx : 0.f);
+            rowacc = fmaf(wx, reg[ri * RLD + ci], rowacc);
+          }
+        }
+        acc = fmaf(wy, rowacc, acc);
+      }
+    }
+    op[(int64_t)(ya + ty) * w + (xa + tx)] = acc;
+  }
+}
+
+static bool plan_bwd(int h, int w, int H, int W, int* TI, int* RMAX, size_t* lds) {
+  const double sh = (double)H / h, sw = (double)W / w;
+  const double s = sh > sw ? sh : sw;
+  for (int t = 16; t >= 1; --t) {
+    const int rm = (int)((t + 1) * s) + 4;
+    const size_t b = sizeof(float) * ((size_t)rm * (rm + 1) + 4 * (size_t)rm + 2 * (size_t)(t + 3));
+    if (rm <= 96 && b <= 48 * 1024) {
+      *TI = t;
+      *RMAX = rm;
+      *lds = b;
+      return true;
+    }
+  }
+  return false;
+}
+
+}  // namespace sea
+
+using namespace sea;
+
+// x: (planes, h, w) -> y: (planes, H, W), H >= h, W >= w
+extern "C" int sea_upsample_bilinear_fwd(const float* x, float* y, int64_t planes, int h, int w, int H, int W,
+                                         void* stream) {
+  SEA_CHECK_ARG(x && y && planes > 0 && h > 0 && w > 0 && H >= h && W >= w);
+  const float rh = (float)h / (float)H, rw = (float)w / (float)W;
+  hipStream_t s = (hipStream_t)stream;
+  for (int64_t p0 = 0; p0 < planes; p0 += 65535) {
+    const int np = (int)((planes - p0) < 65535 ? (planes - p0) : 65535);
+    dim3 grid((W + 63) / 64, (H + 15) / 16, np);
+    hipLaunchKernelGGL(upsample_fwd_kernel, grid, dim3(256), 0, s, x + p0 * h * w, y + p0 * H * W, h, w, H, W, rh, rw);
+  }
+  SEA_RETURN_LAST();
+}
+
+// gy: (planes, H, W) -> gx: (planes, h, w): gradient of sea_upsample_bilinear_fwd w.r.t. its input
+extern "C" int sea_upsample_bilinear_bwd(const float* gy, float* gx, int64_t planes, int h, int w, int H, int W,
+                                         void* stream) {
+  SEA_CHECK_ARG(gy && gx && planes > 0 && h > 0 && w > 0 && H >= h && W >= w);
+  int TI, RMAX;
+  size_t lds;
+  SEA_CHECK_ARG(plan_bwd(h, w, H, W, &TI, &RMAX, &lds));
+  const float rh = (float)h / (float)H, rw = (float)w / (float)W;
+  hipStream_t s = (hipStream_t)stream;
+  for (int64_t p0 = 0; p0 < planes; p0 += 65535) {
+    const int np = (int)((planes - p0) < 65535 ? (planes - p0) : 65535);
+    dim3 grid((w + TI - 1) / TI, (h + TI - 1) / TI, np);
+    hipLaunchKernelGGL(upsample_bwd_kernel, grid, dim3(256), lds, s, gy + p0 * H * W, gx + p0 * h * w, h, w, H, W, rh,
+                       rw, TI, RMAX);
+  }
+  SEA_RETURN_LAST();
+}

@@ -45,6 +45,8 @@ _SIGS = {
     "sea_count_ignored": (_i, [_vp, _i, _i, _i64, _vp, _vp]),
     "sea_worst_miou_greedy": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "sea_dwconv7x7": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sea_upsample_bilinear_fwd": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp]),
+    "sea_upsample_bilinear_bwd": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp]),
 }
 EXPORTS = tuple(_SIGS)
 
@@ -283,6 +285,28 @@ def dwconv7x7(x, weight, bias=None, flip: bool = False):
     _check(lib().sea_dwconv7x7(_p(x), _p(_f32c(weight)), _p(bias), _p(y), B, Cc, H, W, int(flip), _stream()),
            "sea_dwconv7x7")
     return y
+
+
+# ------------------------------------------------------------------------------------------------ M2
+def upsample_bilinear(x, size):
+    """F.interpolate(x, size, mode="bilinear", align_corners=False) for fp32 NCHW device tensors."""
+    _dev(x)
+    x = _f32c(x)
+    B, Cc, h, w = x.shape
+    H, W = int(size[0]), int(size[1])
+    y = torch.empty(B, Cc, H, W, dtype=torch.float32, device=x.device)
+    _check(lib().sea_upsample_bilinear_fwd(_p(x), _p(y), B * Cc, h, w, H, W, _stream()), "sea_upsample_bilinear_fwd")
+    return y
+
+
+def upsample_bilinear_backward(gy, in_size):
+    _dev(gy)
+    gy = _f32c(gy)
+    B, Cc, H, W = gy.shape
+    h, w = int(in_size[0]), int(in_size[1])
+    gx = torch.empty(B, Cc, h, w, dtype=torch.float32, device=gy.device)
+    _check(lib().sea_upsample_bilinear_bwd(_p(gy), _p(gx), B * Cc, h, w, H, W, _stream()), "sea_upsample_bilinear_bwd")
+    return gx
 
 
 # ------------------------------------------------------------------------------------------------ K9 (host)

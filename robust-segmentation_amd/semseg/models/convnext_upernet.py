@@ -194,7 +194,30 @@ class ConvModule(nn.Module):
         return self.activation(self.batch_norm(self.conv(x)))
 
 
+class _UpsampleBilinear(torch.autograd.Function):
+    """Bilinear up-sampling through libsea_hip M2 (forward: one streaming write; backward: deterministic
+    gather)."""
+
+    @staticmethod
+    def forward(ctx, x, size):
+        from .. import _native as N
+        ctx.in_size = tuple(x.shape[2:])
+        return N.upsample_bilinear(x.contiguous(), size)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .. import _native as N
+        return N.upsample_bilinear_backward(gy.contiguous(), ctx.in_size), None
+
+
+USE_HIP_UPSAMPLE = True
+
+
 def _up(x, size):
+    size = tuple(int(v) for v in size)
+    if (USE_HIP_UPSAMPLE and x.is_cuda and x.dtype == torch.float32 and size[0] >= x.shape[2]
+            and size[1] >= x.shape[3]):
+        return _UpsampleBilinear.apply(x, size)
     return F.interpolate(x, size=size, mode="bilinear", align_corners=False)
 
 

@@ -386,3 +386,40 @@ def test_fused_and_unfused_attack_agree(N):
     assert (acc - acc2).abs().max() <= 3.0 / 4096
     torch.testing.assert_close(lb, lb2, rtol=1e-3, atol=1e-4)
     assert ((xba - xba2).abs() > 1e-6).float().mean() < 0.03
+
+
+# ------------------------------------------------------------------------------------------------ M2
+@pytest.mark.parametrize("case", [(2, 8, 16, 16, 32, 32), (1, 4, 32, 32, 128, 128), (2, 3, 16, 16, 128, 128),
+                                  (1, 5, 1, 1, 16, 16), (1, 5, 3, 3, 16, 16), (2, 2, 6, 6, 16, 16),
+                                  (1, 7, 30, 30, 119, 119), (1, 2, 13, 11, 50, 45), (1, 1, 9, 7, 9, 7)])
+def test_upsample_bilinear_forward_backward(N, case):
+    import torch.nn.functional as F
+    B, C, h, w, H, W = case
+    g = torch.Generator().manual_seed(h * 100 + H)
+    x = torch.randn(B, C, h, w, generator=g)
+    xd = x.double().requires_grad_(True)
+    ref = F.interpolate(xd, size=(H, W), mode="bilinear", align_corners=False)
+    gy = torch.randn(B, C, H, W, generator=g)
+    (gx_ref,) = torch.autograd.grad(ref, xd, gy.double())
+    y = N.upsample_bilinear(dev(x), (H, W))
+    torch.testing.assert_close(y.cpu().double(), ref.detach(), rtol=1e-5, atol=1e-5)
+    gx = N.upsample_bilinear_backward(dev(gy), (h, w))
+    torch.testing.assert_close(gx.cpu().double(), gx_ref, rtol=1e-5, atol=1e-4)
+    assert torch.equal(gx, N.upsample_bilinear_backward(dev(gy), (h, w)))  # deterministic gather
+
+
+def test_upernet_head_with_and_without_hip_upsample(N):
+    from semseg.models import convnext_upernet as M
+    torch.manual_seed(0)
+    model = M.UperNetForSemanticSegmentation("ConvNeXt-T_CVST", 21, None).cuda().eval()
+    x = torch.rand(1, 3, 96, 128, device="cuda")
+    outs = []
+    for flag in (True, False):
+        M.USE_HIP_UPSAMPLE = flag
+        xi = x.clone().requires_grad_(True)
+        y = model(xi)
+        (gx,) = torch.autograd.grad(y, xi, torch.ones_like(y))
+        outs.append((y.detach(), gx))
+    M.USE_HIP_UPSAMPLE = True
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-3, atol=1e-6)

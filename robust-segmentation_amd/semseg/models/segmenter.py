@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .convnext_upernet import StochasticDepth
+from .convnext_upernet import StochasticDepth, _up
 
 
 def _init(m):
@@ -223,7 +223,7 @@ class SegMenter(nn.Module):
         H, W = im.shape[2:]
         x = self.encoder(im, pre_neck=True)
         x = x[:, 0 if "SAM" in self.backbone else 1 + int(self.encoder.distilled):]
-        masks = F.interpolate(self.decoder(x, (H, W)), size=(H, W), mode="bilinear")
+        masks = _up(self.decoder(x, (H, W)).contiguous(), (H, W))  # bilinear x16 (libsea_hip M2 on HIP tensors)
         return masks[:, :, :H0, :W0] if (ph or pw) else masks
 
 

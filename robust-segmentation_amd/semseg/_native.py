@@ -45,6 +45,7 @@ _SIGS = {
     "sea_count_ignored": (_i, [_vp, _i, _i, _i64, _vp, _vp]),
     "sea_worst_miou_greedy": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "sea_dwconv7x7": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sea_dwconv7x7_nhwc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sea_nchw_to_nhwc": (_i, [_vp, _vp, _vp, _i, _i, _i64, _vp]),
     "sea_nhwc_to_nchw": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _vp]),
     "sea_upsample_bilinear_fwd": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp]),
@@ -309,6 +310,16 @@ def upsample_bilinear_backward(gy, in_size):
     gx = torch.empty(B, Cc, h, w, dtype=torch.float32, device=gy.device)
     _check(lib().sea_upsample_bilinear_bwd(_p(gy), _p(gx), B * Cc, h, w, H, W, _stream()), "sea_upsample_bilinear_bwd")
     return gx
+
+
+def dwconv7x7_nhwc(x, wt, bias=None, flip: bool = False):
+    """Depthwise 7x7 on a (B,H,W,C) contiguous tensor; wt is the (49,C) taps-major filter bank."""
+    _dev(x, wt, bias)
+    B, H, W, Cc = x.shape
+    y = torch.empty_like(x)
+    _check(lib().sea_dwconv7x7_nhwc(_p(_f32c(x)), _p(_f32c(wt)), _p(bias), _p(y), B, Cc, H, W, int(flip), _stream()),
+           "sea_dwconv7x7_nhwc")
+    return y
 
 
 # ------------------------------------------------------------------------------------------------ M3

@@ -90,6 +90,44 @@ class _DwConv7x7(torch.autograd.Function):
         return gx, gw, gb
 
 
+class _DwConv7x7NHWC(torch.autograd.Function):
+    """Same layer on a (B,H,W,C) contiguous tensor (channels_last trunk): nothing in the block changes
+    layout any more."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, wt):
+        from .. import _native as N
+        ctx.save_for_backward(x, weight, wt)
+        ctx.has_bias = bias is not None
+        return N.dwconv7x7_nhwc(x, wt, bias, flip=False)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .. import _native as N
+        x, weight, wt = ctx.saved_tensors
+        gx = gw = gb = None
+        gy = gy.contiguous()
+        if ctx.needs_input_grad[0]:
+            gx = N.dwconv7x7_nhwc(gy, wt, None, flip=True)
+        if ctx.needs_input_grad[1]:
+            gw = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2), weight.shape, gy.permute(0, 3, 1, 2), padding=3,
+                                             groups=x.shape[-1])
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum((0, 1, 2))
+        return gx, gw, gb, None
+
+
+def _taps_major(conv: nn.Conv2d):
+    """(49, C) copy of the depthwise filter bank, cached until the weight changes."""
+    w = conv.weight
+    key = (w.data_ptr(), w._version, w.device)
+    cached = getattr(conv, "_sea_wt", None)
+    if cached is None or cached[0] != key:
+        cached = (key, w.detach().reshape(w.shape[0], 49).t().contiguous())
+        conv._sea_wt = cached
+    return cached[1]
+
+
 def depthwise7x7(conv: nn.Conv2d, x):
     """Route fp32 HIP tensors through the stencil kernel, everything else through nn.Conv2d."""
     if x.is_cuda and x.dtype == torch.float32 and conv.weight.dtype == torch.float32 and USE_HIP_DWCONV:
@@ -142,6 +180,7 @@ class _ScaleResidual(torch.autograd.Function):
 
 
 USE_HIP_TRANSPOSE = True
+STAGE_ENTRY_CONTIGUOUS = False  # the trunk arrives channels_last from MIOpen; Block has an all-NHWC path for that
 
 
 def _fast_layout_ok(x):
@@ -177,8 +216,18 @@ class Block(nn.Module):
         self.drop_path = StochasticDepth(drop_path) if drop_path > 0 else nn.Identity()
 
     def forward(self, x):
-        y = depthwise7x7(self.dwconv, x)
         no_drop = isinstance(self.drop_path, nn.Identity) or not self.training
+        if (USE_HIP_DWCONV and no_drop and x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 4 == 0
+                and x.shape[1] <= 1024 and not x.is_contiguous()
+                and x.is_contiguous(memory_format=torch.channels_last)):
+            # channels_last trunk (what MIOpen's NHWC convolutions hand us): the whole block stays in NHWC
+            xn = x.permute(0, 2, 3, 1)  # contiguous (B,H,W,C) view
+            y = _DwConv7x7NHWC.apply(xn, self.dwconv.weight, self.dwconv.bias, _taps_major(self.dwconv))
+            y = self.pwconv2(self.act(self.pwconv1(self.norm(y))))
+            if self.gamma is not None:
+                y = self.gamma * y
+            return (xn + y).permute(0, 3, 1, 2)
+        y = depthwise7x7(self.dwconv, x)
         if no_drop and _fast_layout_ok(x) and y.is_contiguous():
             # NCHW -> NHWC and back through the tiled transposes, layer scale + residual fused into the second
             y = self.pwconv2(self.act(self.pwconv1(self.norm(_ToNHWC.apply(y)))))
@@ -228,7 +277,10 @@ class ConvNeXt(nn.Module):
     def forward(self, x):
         feats = []
         for i in range(4):
-            x = self.stages[i](self.downsample_layers[i](x))
+            x = self.downsample_layers[i](x)
+            if STAGE_ENTRY_CONTIGUOUS and not x.is_contiguous():
+                x = x.contiguous()  # the blocks' stencil / transpose kernels want NCHW planes
+            x = self.stages[i](x)
             if i in self.out_indices:
                 feats.append(getattr(self, f"norm{i}")(x))
         return tuple(feats)

@@ -467,3 +467,45 @@ def test_convnext_block_fast_layout_path_matches_plain_path(N):
     M.USE_HIP_TRANSPOSE = True
     for a, b in zip(*outs):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("shape", [(2, 96, 64, 64), (1, 768, 16, 16), (2, 192, 33, 21), (1, 4, 7, 70), (2, 384, 32, 32)])
+def test_dwconv7x7_nhwc_forward_and_backward_data(N, shape):
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(shape[1] + 1)
+    B, C, H, W = shape
+    x = torch.randn(shape, generator=g)
+    w = torch.randn(C, 1, 7, 7, generator=g) * 0.1
+    b = torch.randn(C, generator=g)
+    xd = x.double().requires_grad_(True)
+    ref = F.conv2d(xd, w.double(), b.double(), padding=3, groups=C)
+    gy = torch.randn(ref.shape, generator=g)
+    (gx_ref,) = torch.autograd.grad(ref, xd, gy.double())
+    wt = w.view(C, 49).t().contiguous()
+    y = N.dwconv7x7_nhwc(dev(x.permute(0, 2, 3, 1).contiguous()), dev(wt), dev(b))
+    torch.testing.assert_close(y.cpu().permute(0, 3, 1, 2).double(), ref.detach(), rtol=1e-5, atol=1e-5)
+    gx = N.dwconv7x7_nhwc(dev(gy.permute(0, 2, 3, 1).contiguous()), dev(wt), None, flip=True)
+    torch.testing.assert_close(gx.cpu().permute(0, 3, 1, 2).double(), gx_ref, rtol=1e-5, atol=1e-5)
+
+
+def test_convnext_block_channels_last_path(N):
+    """the all-NHWC block path (channels_last input) equals the plain PyTorch block, incl. parameter grads"""
+    from semseg.models import convnext_upernet as M
+    torch.manual_seed(1)
+    blk = M.Block(192).cuda().eval()
+    with torch.no_grad():
+        blk.gamma.mul_(torch.rand(192, device="cuda") + 0.5)
+    x = torch.randn(2, 192, 24, 40, device="cuda").contiguous(memory_format=torch.channels_last)
+    outs = []
+    for flag in (True, False):
+        M.USE_HIP_DWCONV = flag
+        for p in blk.parameters():
+            p.grad = None
+        xi = x.clone(memory_format=torch.preserve_format).requires_grad_(True)
+        y = blk(xi)
+        y.square().sum().backward()
+        outs.append((y.detach(), xi.grad, blk.gamma.grad.clone(), blk.dwconv.weight.grad.clone(), blk.dwconv.bias.grad.clone()))
+    M.USE_HIP_DWCONV = True
+    assert outs[0][0].is_contiguous(memory_format=torch.channels_last)
+    for a, b in zip(*outs):
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-4 * b.abs().max().item())

@@ -32,10 +32,20 @@ def k2_algorithmic_bytes(B, C, HW, logit_bytes=4, with_grad=True):
     return B * HW * ((2 if with_grad else 1) * C * logit_bytes + 16)
 
 
-def build_case(rank, B, C, backbone, device):
+def make_model(backbone, C):
+    """UperNet-ConvNeXt (BASELINE configs 1, 2, 4, 5) or Segmenter ViT (config 3: --backbone vit_small_patch16_224)."""
+    if backbone.startswith("vit_"):
+        from semseg.models import create_segmenter
+        from semseg.utils.utils import load_config_segmenter
+        cfg, _ = load_config_segmenter(backbone, C)
+        return create_segmenter(cfg, None, backbone)
     from semseg.models import UperNetForSemanticSegmentation
+    return UperNetForSemanticSegmentation(backbone, C, None)
+
+
+def build_case(rank, B, C, backbone, device):
     torch.manual_seed(0)  # identical weights on every rank
-    model = UperNetForSemanticSegmentation(backbone, C, None).eval().to(device)
+    model = make_model(backbone, C).eval().to(device)
     for p in model.parameters():
         p.requires_grad_(False)
     g = torch.Generator().manual_seed(1234 + rank)
@@ -49,10 +59,9 @@ def cpu_baseline(C, backbone, loss, eps, B=2, n_iter=3):
     """The oracle's APGD loop (the restated reference path) on the host cores, bounded sample
     (about 10-30 s): step 0 + n_iter loop iterations on B images."""
     from oracle import sea_oracle as O
-    from semseg.models import UperNetForSemanticSegmentation
     from semseg.utils.utils import ADE_WTS, VOC_WTS
     torch.manual_seed(0)
-    model = UperNetForSemanticSegmentation(backbone, C, None).eval()
+    model = make_model(backbone, C).eval()
     cores = min(os.cpu_count() or 1, 32)  # more threads than that slow PyTorch-CPU convolutions down
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(1234)
@@ -66,7 +75,7 @@ def cpu_baseline(C, backbone, loss, eps, B=2, n_iter=3):
     # (1 + n_iter) forwards and n_iter backwards ran (the last iteration has no backward, like the
     # reference); every pass is counted as an iteration here, which favours the CPU number
     return {"value": B * (n_iter + 1) / dt, "unit": "image-iterations/s", "cores": cores, "kind": "port",
-            "sample": f"oracle apgd_train (PyTorch-CPU restatement of the reference loop), UperNet-{backbone}, "
+            "sample": f"oracle apgd_train (PyTorch-CPU restatement of the reference loop), {backbone}, "
                       f"B={B}x512x512, C={C}, step 0 + {n_iter} iteration(s), {loss}, {dt:.1f} s wall"}
 
 
@@ -132,6 +141,7 @@ def main():
 
     k2_ms = sum(a.elapsed_time(b) for a, b in run.k2_events) / max(len(run.k2_events), 1)
     algo = k2_algorithmic_bytes(B, C, 512 * 512)
+    kname = "loss_upsampled_kernel (K2u)" if args.fuse_upsample else f"loss_nchw_reg<C={C}> (K2 fused loss fwd+bwd)"
     achieved = algo / (k2_ms * 1e-3) / 1e9
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "k2_traffic.json")
@@ -151,12 +161,13 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"UperNet-{args.backbone} PASCAL-VOC-shaped C={C}, {B}x512x512 per GPU, APGD L-inf "
+                "workload": f"{'Segmenter-' if args.backbone.startswith('vit_') else 'UperNet-'}{args.backbone} C={C} "
+                            f"({'PASCAL-VOC' if C == 21 else 'ADE20K'}-shaped), {B}x512x512 per GPU, APGD L-inf "
                             f"eps={args.eps:g}/255, loss {args.loss}, track ce-avg (BASELINE configs[1] loop body)",
                 "batch_per_gpu": B, "global_batch": world * B, "sharding": f"images x{world}, no in-loop collective",
                 "batch_steps_per_s": world * K / dt,
             },
-            "roofline": {"kernel": "loss_upsampled_kernel (K2u)" if args.fuse_upsample else "loss_nchw_reg (K2 fused loss fwd+bwd)", "bound": "hbm", "achieved": achieved,
+            "roofline": {"kernel": kname, "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes": algo, "avg_launch_ms": k2_ms},
         }

@@ -91,7 +91,8 @@ def main():
     ap.add_argument("--eps", type=float, default=8.0, help="radius in 1/255 (SEA stage-1 radius for eps=4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fuse-upsample", action="store_true",
-                    help="use K2u (loss fused with the model's final bilinear upsample) instead of upsample + K2")
+                    help="force K2u (loss fused with the model's final bilinear upsample); default: the library's "
+                         "heuristic (fused for upsample factors >= 8, i.e. Segmenter; unfused for UperNet)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,7 +118,7 @@ def main():
     # default: the model's own upsample + the HBM-bound K2 (the kernel SURVEY 8d prices); --fuse-upsample
     # switches to K2u, which is ~0.1 ms/step faster at C=21 and ~5 ms/step on Segmenter (x16, C=151)
     run = A.ApgdRun(model, x, y, eps, W + K + 1, args.loss, "ce-avg", True, C, weights, x.clone(),
-                    fuse_upsample=args.fuse_upsample)
+                    fuse_upsample=True if args.fuse_upsample else None)
     run.start()
     for i in range(W):
         run.step(i)
@@ -141,7 +142,7 @@ def main():
 
     k2_ms = sum(a.elapsed_time(b) for a, b in run.k2_events) / max(len(run.k2_events), 1)
     algo = k2_algorithmic_bytes(B, C, 512 * 512)
-    kname = "loss_upsampled_kernel (K2u)" if args.fuse_upsample else f"loss_nchw_reg<C={C}> (K2 fused loss fwd+bwd)"
+    kname = "loss_upsampled_kernel (K2u)" if run.fused else f"loss_nchw_reg<C={C}> (K2 fused loss fwd+bwd)"
     achieved = algo / (k2_ms * 1e-3) / 1e9
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "k2_traffic.json")

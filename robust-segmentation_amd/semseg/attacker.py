@@ -232,11 +232,13 @@ def _input_grad(logits, x_in, dlogits):
     return g if g.is_contiguous() else g.contiguous()
 
 
-# Module switch for K2u (loss fused with the model's final bilinear upsample, needs `model.forward_lowres`).
-# Off by default: with the streaming upsample kernels M2 the unfused path (upsample -> K2 -> upsample-backward)
-# is as fast at C=21 and faster at C=151; K2u remains the choice when HBM capacity matters (it never
-# materialises the (B,C,H,W) logits and their gradient: 2.5 GB at B=8, C=151, 512x512).
-FUSE_UPSAMPLE = False
+# K2u (loss fused with the model's final bilinear upsample; needs `model.forward_lowres`).
+#   "auto": fuse when the upsample factor is >= 8.  Measured on MI355X (B=8, 512x512): Segmenter ViT-S/16, C=151
+#           26.1 ms/step fused vs 32.6 ms unfused (the x16 upsample of a 1.27 GB logit tensor and its backward
+#           dominate); UperNet x4: the streaming upsample kernels M2 + K2 are as fast (C=21) or faster (C=151).
+#   True / False force it.  K2u also never materialises the (B,C,H,W) logits and their gradient
+#   (2.5 GB at B=8, C=151).
+FUSE_UPSAMPLE = "auto"
 
 
 class ApgdRun:
@@ -249,10 +251,16 @@ class ApgdRun:
         self.model = model
         # fuse the model's final bilinear upsample into the loss kernel when the model offers the hook
         if fuse_upsample is None:
-            fuse_upsample = FUSE_UPSAMPLE and hasattr(model, "forward_lowres")
-        if fuse_upsample:
+            fuse_upsample = FUSE_UPSAMPLE
+        if fuse_upsample and hasattr(model, "forward_lowres"):
             with torch.no_grad():
-                fuse_upsample = model.forward_lowres(x[:1]) is not None
+                probe = model.forward_lowres(x[:1])
+            if probe is None:
+                fuse_upsample = False
+            elif fuse_upsample == "auto":
+                fuse_upsample = x.shape[-1] / probe[0].shape[-1] >= 8
+        else:
+            fuse_upsample = False
         self.fused = bool(fuse_upsample)
         self.mode = N.MODE_BY_NAME[loss]
         self.tmode = N.MODE_BY_NAME[track_loss] if track_loss is not None else self.mode

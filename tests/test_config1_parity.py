@@ -66,4 +66,4 @@ def test_config1_device_path_matches_reference():
             pa = model(xa).max(1)[1]
         m_acc, a_acc, m_iou = A.compute_iou_acc(pa, y.cuda(), 21)
         assert abs(a_acc.item() - g["adv_aacc"]) <= 5e-3 and abs(m_iou.item() - g["adv_miou"]) <= 1e-2
-    A.FUSE_UPSAMPLE = False
+    A.FUSE_UPSAMPLE = "auto"

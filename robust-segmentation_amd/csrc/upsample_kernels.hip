@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restri
   }
 }
 
-// grid = (tiles_x, tiles_y, planes); dynamic LDS: go region [RMAX][RLD] + axis tables + cell tables
+// grid = (tiles_x, tiles_y, planes); dynamic LDS: go region [RMAX][RLD] + axis tables + cell tables + row sums
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int h,
                                                            int w, int H, int W, float rh, float rw, int TI, int RMAX) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
   float* c_lam = (float*)(c_i1 + RMAX);
   int* rbeg = (int*)(c_lam + RMAX);          // TI + 3
   int* cbeg = rbeg + (TI + 3);
+  float* tmp = (float*)(cbeg + (TI + 3));    // RMAX * (TI + 1): row-reduced partial sums
   const int plane = blockIdx.z;
   const int ya = blockIdx.y * TI, xa = blockIdx.x * TI;
   const int yb = min(ya + TI, h), xb = min(xa + TI, w);
@@ -113,10 +114,30 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
   }
   __syncthreads();
   const int nly = yb - ya, nlx = xb - xa;
+  // separable gather: first along x (per region row), then along y
+  const int TLD = TI + 1;
+  for (int item = threadIdx.x; item < RH * nlx; item += 256) {
+    const int ri = item / nlx, tx = item - ri * nlx;
+    const int xl = tx + 1;
+    float rowacc = 0.f;
+    for (int qx = 0; qx < 2; ++qx) {
+      const int cx = xl - 1 + qx;
+      const int j_lo = cbeg[cx] - X0, j_hi = cbeg[cx + 1] - X0;
+      if (j_lo >= j_hi) continue;
+      const int cx1 = c_i1[j_lo];
+      for (int ci = j_lo; ci < j_hi; ++ci) {
+        const float lx = c_lam[ci];
+        const float wx = ((cx == xl) ? (1.f - lx) : 0.f) + ((cx1 == xl) ? lx : 0.f);
+        rowacc = fmaf(wx, reg[ri * RLD + ci], rowacc);
+      }
+    }
+    tmp[ri * TLD + tx] = rowacc;
+  }
+  __syncthreads();
   float* op = gx + (int64_t)plane * h * w;
   for (int item = threadIdx.x; item < nly * nlx; item += 256) {
     const int ty = item / nlx, tx = item - ty * nlx;
-    const int yl = ty + 1, xl = tx + 1;
+    const int yl = ty + 1;
     float acc = 0.f;
     for (int qy = 0; qy < 2; ++qy) {
       const int cy = yl - 1 + qy;
@@ -126,20 +147,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
       for (int ri = i_lo; ri < i_hi; ++ri) {
         const float ly = r_lam[ri];
         const float wy = ((cy == yl) ? (1.f - ly) : 0.f) + ((cy1 == yl) ? ly : 0.f);
-        if (wy == 0.f) continue;
-        float rowacc = 0.f;
-        for (int qx = 0; qx < 2; ++qx) {
-          const int cx = xl - 1 + qx;
-          const int j_lo = cbeg[cx] - X0, j_hi = cbeg[cx + 1] - X0;
-          if (j_lo >= j_hi) continue;
-          const int cx1 = c_i1[j_lo];
-          for (int ci = j_lo; ci < j_hi; ++ci) {
-            const float lx = c_lam[ci];
-            const float wx = ((cx == xl) ? (1.f - lx) : 0.f) + ((cx1 == xl) ? lx : 0.f);
-            rowacc = fmaf(wx, reg[ri * RLD + ci], rowacc);
-          }
-        }
-        acc = fmaf(wy, rowacc, acc);
+        acc = fmaf(wy, tmp[ri * TLD + tx], acc);
       }
     }
     op[(int64_t)(ya + ty) * w + (xa + tx)] = acc;
@@ -151,7 +159,7 @@ static bool plan_bwd(int h, int w, int H, int W, int* TI, int* RMAX, size_t* lds
   const double s = sh > sw ? sh : sw;
   for (int t = 32; t >= 1; --t) {
     const int rm = (int)((t + 1) * s) + 4;
-    const size_t b = sizeof(float) * ((size_t)rm * (rm + 1) + 4 * (size_t)rm + 2 * (size_t)(t + 3));
+    const size_t b = sizeof(float) * ((size_t)rm * (rm + 1) + 4 * (size_t)rm + 2 * (size_t)(t + 3) + (size_t)rm * (t + 1));
     if (rm <= 96 && b <= 48 * 1024) {
       *TI = t;
       *RMAX = rm;

@@ -116,10 +116,13 @@ extern "C" int sea_confusion(const void* pred, int pred_bytes, const void* y, in
   SEA_CHECK_ARG(width_ok(pred_bytes) && width_ok(y_bytes));
   const size_t lds = (size_t)C * C * sizeof(int);
   const int g = grid_for(n, 256 * 32);
-  if (lds <= 64 * 1024)
-    hipLaunchKernelGGL(confusion_kernel<true>, dim3(g), dim3(256), lds, (hipStream_t)stream, pred, pred_bytes, y,
-                       y_bytes, n, C, (unsigned long long*)hist);
-  else
+  if (lds <= 150 * 1024) {  // C <= 195: the K x K histogram is privatised in LDS (ADE20K's 151 classes need 91 KB)
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)confusion_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+    hipLaunchKernelGGL(confusion_kernel<true>, dim3(lds > 64 * 1024 ? (g > 512 ? 512 : g) : g), dim3(256), lds,
+                       (hipStream_t)stream, pred, pred_bytes, y, y_bytes, n, C, (unsigned long long*)hist);
+  } else
     hipLaunchKernelGGL(confusion_kernel<false>, dim3(g), dim3(256), 0, (hipStream_t)stream, pred, pred_bytes, y,
                        y_bytes, n, C, (unsigned long long*)hist);
   SEA_RETURN_LAST();

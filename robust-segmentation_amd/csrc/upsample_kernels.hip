@@ -98,9 +98,24 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
   const int Y0 = rbeg[0], Y1 = rbeg[TI + 2], X0 = cbeg[0], X1 = cbeg[TI + 2];
   const int RH = Y1 - Y0, RW = X1 - X0;
   const float* gp = gy + (int64_t)plane * H * W;
-  for (int ri = threadIdx.x / 64; ri < RH; ri += 4) {        // one wave per region row: coalesced row reads
-    const float* src = gp + (int64_t)(Y0 + ri) * W + X0;
-    for (int ci = threadIdx.x & 63; ci < RW; ci += 64) reg[ri * RLD + ci] = src[ci];
+  // stage the region: 8 independent loads in flight per lane before the first LDS write (a plain
+  // load->store loop serialises on the HBM latency: measured 10x slower than the roofline)
+  {
+    const int total = RH * RW;
+    for (int base = 0; base < total; base += 256 * 8) {
+      float v[8];
+      int dst[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int idx = base + k * 256 + threadIdx.x;
+        const int ri = idx / RW, ci = idx - ri * RW;
+        dst[k] = idx < total ? ri * RLD + ci : -1;
+        v[k] = idx < total ? gp[(int64_t)(Y0 + ri) * W + X0 + ci] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (dst[k] >= 0) reg[dst[k]] = v[k];
+    }
   }
   for (int i = threadIdx.x; i < RH; i += 256) {
     const AxisMapU m = axis_map_u(Y0 + i, rh, h);
@@ -157,10 +172,12 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
 static bool plan_bwd(int h, int w, int H, int W, int* TI, int* RMAX, size_t* lds) {
   const double sh = (double)H / h, sw = (double)W / w;
   const double s = sh > sw ? sh : sw;
-  for (int t = 32; t >= 1; --t) {
+  // power-of-two input tiles (feature maps are powers of two: no ragged border tiles), region <= 80x80
+  // full-res pixels (~25 KB of LDS -> 6 workgroups per CU)
+  for (int t = 32; t >= 1; t >>= 1) {
     const int rm = (int)((t + 1) * s) + 4;
     const size_t b = sizeof(float) * ((size_t)rm * (rm + 1) + 4 * (size_t)rm + 2 * (size_t)(t + 3) + (size_t)rm * (t + 1));
-    if (rm <= 96 && b <= 48 * 1024) {
+    if (rm <= 80 && b <= 48 * 1024) {
       *TI = t;
       *RMAX = rm;
       *lds = b;

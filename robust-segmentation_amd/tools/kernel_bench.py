@@ -159,6 +159,32 @@ def main():
     for k, ms in t.items():
         report(k, ms, mult[k.split()[0]] * n)
 
+    # ---------------- M2 / M1 (model side) ---------------------------------------------------------------
+    import torch.nn.functional as F
+    for Cc, hl, Hh in ((512, 64, 128), (512, 32, 128), (512, 16, 128), (512, 32, 64), (512, 16, 32), (21, 128, 512)):
+        xin = torch.randn(B, Cc, hl, hl, device="cuda")
+        gy = torch.randn(B, Cc, Hh, Hh, device="cuda")
+        t = timeit({
+            f"M2 upsample fwd {Cc}ch {hl}->{Hh}": lambda: N.upsample_bilinear(xin, (Hh, Hh)),
+            f"M2 upsample bwd {Cc}ch {hl}->{Hh}": lambda: N.upsample_bilinear_backward(gy, (hl, hl)),
+            f"ATen upsample fwd {Cc}ch {hl}->{Hh}": lambda: F.interpolate(xin, size=(Hh, Hh), mode="bilinear", align_corners=False),
+        }, rounds=7)
+        for k, ms in t.items():
+            report(k, ms, 4 * (xin.numel() + gy.numel()))
+    for Cc, hw in ((96, 128), (192, 64), (384, 32), (768, 16)):
+        xn = torch.randn(B, hw, hw, Cc, device="cuda")
+        xc = torch.randn(B, Cc, hw, hw, device="cuda")
+        wt = torch.randn(49, Cc, device="cuda") * 0.1
+        wc = torch.randn(Cc, 1, 7, 7, device="cuda") * 0.1
+        bb = torch.randn(Cc, device="cuda")
+        t = timeit({
+            f"M1 dwconv7x7 NHWC C={Cc} {hw}x{hw} fwd": lambda: N.dwconv7x7_nhwc(xn, wt, bb),
+            f"M1 dwconv7x7 NHWC C={Cc} {hw}x{hw} bwd-data": lambda: N.dwconv7x7_nhwc(xn, wt, None, flip=True),
+            f"M1 dwconv7x7 NCHW C={Cc} {hw}x{hw} fwd": lambda: N.dwconv7x7(xc, wc, bb),
+        }, rounds=7)
+        for k, ms in t.items():
+            report(k, ms, 8 * xn.numel())
+
     # ---------------- K3 ----------------------------------------------------------------------------
     for C in (21, 151):
         pred = torch.randint(0, C, (B, H, W), device="cuda", dtype=torch.uint8)

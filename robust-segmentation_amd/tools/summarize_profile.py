@@ -30,8 +30,11 @@ def short(name, n=110):
 
 def sea_key(n):
     if "loss_nchw_reg" in n:
-        m = re.search(r"loss_nchw_reg<(\w+), (\d+), (\d+), (\w+), (\w+)>", n)
-        return f"K2 loss_nchw_reg<{m.group(1)},C={m.group(2)},vec={m.group(3)},grad={m.group(4)}>" if m else "K2 loss_nchw_reg"
+        m = re.search(r"loss_nchw_reg<(\w+), (\d+), (\d+), (\w+), (\w+)(?:, (\d+))?>", n)
+        if not m:
+            return "K2 loss_nchw_reg"
+        tune = f",tune={m.group(6)}" if m.group(6) else ""
+        return f"K2 loss_nchw_reg<{m.group(1)},C={m.group(2)},vec={m.group(3)},grad={m.group(4)}{tune}>"
     for pat, key in (("loss_nhwc_lds", "K2 loss_nhwc_lds"), ("loss_nchw_stream", "K2 loss_nchw_stream"),
                      ("loss_finalize", "K2 loss_finalize"), ("apgd_linf_step", "K1 apgd_linf_step"),
                      ("pgd_linf_step", "K6 pgd_linf_step"), ("ew2_v", "K5 random_start/project"),

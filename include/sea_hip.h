@@ -94,6 +94,9 @@ int sea_pgd_linf_step(const float* X, const float* delta, const float* grad, flo
  *   loss_sum / track_sum (B) float32: SUM over the image's pixels of the attack / tracking loss
  *            (the caller divides by H*W; attacker.py:240 divides by all pixels incl. ignored)
  *   n_correct (B) int32: #valid pixels with argmax == label
+ *   Passing loss_sum = track_sum = n_correct = NULL defers the second reduction stage: the per-block
+ *   records stay in `workspace` and sea_apgd_track (K7) sums them itself (`loss_workspace` argument), which
+ *   saves one launch per APGD iteration.
  * Reductions are two-stage with a fixed order (no float atomics): results are run-to-run
  * deterministic.
  */
@@ -151,7 +154,8 @@ int sea_confusion(const void* pred, int pred_bytes, const void* y, int y_bytes, 
  * sea_apgd_track: one tiny launch per iteration.  replaces semseg/attacker.py:370-383 (init=1),
  *   485-495 (best-adv tracking), 520-526 (best-loss tracking), 243-248 + 528-551 (oscillation
  *   check and step halving) and 568-569 (early stop, as a device flag).
- *     loss_sum/track_sum/n_correct  outputs of K2 for this iterate;  n_ignored (B) #ignored pixels
+ *     loss_sum/track_sum/n_correct  outputs of K2 for this iterate (or NULL + loss_workspace = the K2
+ *               workspace of a deferred K2 call);  n_ignored (B) #ignored pixels
  *     iter      loop index i (ignored when init=1);  n_iter rows in loss_steps
  *     check_k   0, or the window k when this iteration is a checkpoint (schedule is data
  *               independent, attacker.py:528-551, so the host knows it)
@@ -170,7 +174,7 @@ int sea_apgd_track(const float* loss_sum, const float* track_sum, const int32_t*
                    const int32_t* n_ignored, int B, int64_t HW, int iter, int n_iter, int check_k,
                    int early_stop, int init, int32_t* acc_cnt, float* acc, float* loss_best,
                    float* loss_best_last, float* reduced_last, float* step, float* loss_steps,
-                   uint8_t* flags, int32_t* done, void* stream);
+                   uint8_t* flags, int32_t* done, const void* loss_workspace, void* stream);
 int sea_select_copy(const uint8_t* flags, float* x_adv, float* grad, float* x_best,
                     float* grad_best, float* x_best_adv, const void* pred, void* pred_best,
                     int pred_bytes, int B, int64_t n_per_img, int64_t HW, void* stream);

@@ -9,24 +9,64 @@
 
 namespace sea {
 
+// must match BlockPartial of loss_kernels.hip
+struct __attribute__((aligned(16))) LossRecord {
+  float loss, track;
+  int n_correct, pad;
+};
+
 __global__ __launch_bounds__(256) void apgd_track_kernel(
     const float* __restrict__ loss_sum, const float* __restrict__ track_sum, const int32_t* __restrict__ n_correct,
     const int32_t* __restrict__ n_ignored, int B, int64_t HW, int iter, int n_iter, int check_k, int early_stop,
     int init, int32_t* __restrict__ acc_cnt, float* __restrict__ acc, float* __restrict__ loss_best,
     float* __restrict__ loss_best_last, float* __restrict__ reduced_last, float* __restrict__ step,
-    float* __restrict__ loss_steps, uint8_t* __restrict__ flags, int32_t* __restrict__ done) {
+    float* __restrict__ loss_steps, uint8_t* __restrict__ flags, int32_t* __restrict__ done,
+    const LossRecord* __restrict__ records) {
   __shared__ int s_any_nonzero;
+  __shared__ double s_t[256];
+  __shared__ int s_n[256];
+  __shared__ float s_track[1024];
+  __shared__ int s_corr[1024];
   if (threadIdx.x == 0) s_any_nonzero = 0;
+  // Deferred K2 reduction: sum the per-block records of every image here (fixed order, double), so the
+  // loop needs no separate finalize launch.  records[0] is the header {.,., tiles, images}.
+  if (records != nullptr) {
+    const int tiles = records[0].n_correct;
+    for (int b = 0; b < B && b < 1024; ++b) {
+      double t = 0.0;
+      int n = 0;
+      for (int i = threadIdx.x; i < tiles; i += blockDim.x) {
+        const LossRecord r = records[1 + (int64_t)b * tiles + i];
+        t += (double)r.track;
+        n += r.n_correct;
+      }
+      s_t[threadIdx.x] = t;
+      s_n[threadIdx.x] = n;
+      __syncthreads();
+      for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+          s_t[threadIdx.x] += s_t[threadIdx.x + o];
+          s_n[threadIdx.x] += s_n[threadIdx.x + o];
+        }
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) {
+        s_track[b] = (float)s_t[0];
+        s_corr[b] = s_n[0];
+      }
+      __syncthreads();
+    }
+  }
   __syncthreads();
   const bool frozen = (*done != 0);
   for (int b = threadIdx.x; b < B; b += blockDim.x) {
     uint8_t f_adv = 0, f_best = 0, f_restart = 0;
     if (!frozen) {
       // per-image mean over ALL pixels (pixel_to_img_loss, attacker.py:237-240)
-      const float track = track_sum[b] / (float)HW;
+      const float track = (records ? s_track[b] : track_sum[b]) / (float)HW;
       if (init) {
         // step 0 (attacker.py:370-383): ignored pixels count as wrong, everything is "best so far"
-        const int cnt = n_correct[b];
+        const int cnt = records ? s_corr[b] : n_correct[b];
         acc_cnt[b] = cnt;
         acc[b] = (float)cnt / (float)HW;
         loss_best[b] = track;
@@ -34,7 +74,7 @@ __global__ __launch_bounds__(256) void apgd_track_kernel(
         reduced_last[b] = 1.f;
       } else {
         // best-adv tracking (attacker.py:485-495): ignored pixels count as correct; <= keeps the latest
-        const int cnt = n_correct[b] + n_ignored[b];
+        const int cnt = (records ? s_corr[b] : n_correct[b]) + n_ignored[b];
         const int best = acc_cnt[b];
         if (cnt <= best) {
           f_adv = 1;
@@ -168,14 +208,17 @@ extern "C" int sea_apgd_track(const float* loss_sum, const float* track_sum, con
                               const int32_t* n_ignored, int B, int64_t HW, int iter, int n_iter, int check_k,
                               int early_stop, int init, int32_t* acc_cnt, float* acc, float* loss_best,
                               float* loss_best_last, float* reduced_last, float* step, float* loss_steps,
-                              uint8_t* flags, int32_t* done, void* stream) {
-  SEA_CHECK_ARG(track_sum && n_correct && acc_cnt && acc && loss_best && loss_best_last && reduced_last && step &&
-                flags && done && B > 0 && HW > 0);
+                              uint8_t* flags, int32_t* done, const void* loss_workspace, void* stream) {
+  SEA_CHECK_ARG(acc_cnt && acc && loss_best && loss_best_last && reduced_last && step && flags && done && B > 0 &&
+                HW > 0);
+  // either the reduced K2 outputs or the K2 workspace holding the per-block records (deferred mode)
+  SEA_CHECK_ARG((track_sum && n_correct) || (loss_workspace && B <= 1024));
   SEA_CHECK_ARG(init || (n_ignored && loss_steps && iter >= 0 && n_iter > 0 && iter < n_iter));
   SEA_CHECK_ARG(check_k >= 0);
   hipLaunchKernelGGL(apgd_track_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_sum, track_sum, n_correct,
                      n_ignored, B, HW, iter, n_iter, check_k, early_stop, init, acc_cnt, acc, loss_best,
-                     loss_best_last, reduced_last, step, loss_steps, flags, done);
+                     loss_best_last, reduced_last, step, loss_steps, flags, done,
+                     (track_sum && n_correct) ? (const LossRecord*)nullptr : (const LossRecord*)loss_workspace);
   SEA_RETURN_LAST();
 }
 

@@ -101,8 +101,11 @@ __device__ __forceinline__ float grad_coef(int mode, bool valid, bool correct, f
   return correct ? wy : 0.f;
 }
 
-// block reduction of the three per-thread sums and record write (fixed order, deterministic)
-__device__ __forceinline__ void block_reduce_store(float ls, float ts, int nc, BlockPartial* dst) {
+// block reduction of the three per-thread sums and record write (fixed order, deterministic).
+// Workspace layout: record 0 is a header {tiles per image, images, 0, 0} written by block (0,0); the
+// per-block records follow, image-major.  The header lets the consumer (loss_finalize or the APGD
+// bookkeeping kernel K7) find its way without the host knowing which tiling the dispatcher chose.
+__device__ __forceinline__ void block_reduce_store(float ls, float ts, int nc, BlockPartial* ws) {
   __shared__ float s_l[4], s_t[4];
   __shared__ int s_n[4];
   ls = wave_sum(ls);
@@ -121,7 +124,15 @@ __device__ __forceinline__ void block_reduce_store(float ls, float ts, int nc, B
     p.track = (s_t[0] + s_t[1]) + (s_t[2] + s_t[3]);
     p.n_correct = s_n[0] + s_n[1] + s_n[2] + s_n[3];
     p.pad = 0;
-    *dst = p;
+    ws[1 + (int64_t)blockIdx.y * gridDim.x + blockIdx.x] = p;
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+      BlockPartial hdr;
+      hdr.loss = 0.f;
+      hdr.track = 0.f;
+      hdr.n_correct = (int)gridDim.x;  // tiles per image
+      hdr.pad = (int)gridDim.y;        // images
+      ws[0] = hdr;
+    }
   }
 }
 
@@ -283,7 +294,7 @@ __global__ __launch_bounds__(256, (TUNE & 4) ? 4 : 1) void loss_nchw_reg(const T
       }
     }
   }
-  block_reduce_store(lsum, tsum, ncorr, partials + (int64_t)b * gridDim.x + blockIdx.x);
+  block_reduce_store(lsum, tsum, ncorr, partials);
 }
 
 // ---- NCHW, any C: two passes over the class planes (second pass re-reads; used only when the class
@@ -346,7 +357,7 @@ __global__ __launch_bounds__(256) void loss_nchw_stream(const T* __restrict__ lo
       }
     }
   }
-  block_reduce_store(lsum, tsum, ncorr, partials + (int64_t)b * gridDim.x + blockIdx.x);
+  block_reduce_store(lsum, tsum, ncorr, partials);
 }
 
 // ---- NHWC (channels_last logits): the class vector of a pixel is contiguous -----------------------
@@ -423,7 +434,7 @@ __global__ __launch_bounds__(256) void loss_nhwc_lds(const T* __restrict__ logit
       dst[i] = Elem<T>::from_f(tile[p * CS + c]);
     }
   }
-  block_reduce_store(lsum, tsum, ncorr, partials + (int64_t)b * gridDim.x + blockIdx.x);
+  block_reduce_store(lsum, tsum, ncorr, partials);
 }
 
 // ---- second stage: fixed-order sum of the per-block records of each image ------------------------
@@ -436,7 +447,7 @@ __global__ __launch_bounds__(256) void loss_finalize(const BlockPartial* __restr
   double l = 0.0, t = 0.0;
   int n = 0;
   for (int i = threadIdx.x; i < tiles; i += 256) {
-    const BlockPartial p = partials[(int64_t)b * tiles + i];
+    const BlockPartial p = partials[1 + (int64_t)b * tiles + i];
     l += (double)p.loss;
     t += (double)p.track;
     n += p.n_correct;
@@ -644,7 +655,11 @@ static int loss_fwd_bwd_impl(const void* logits, int dtype, int layout, const vo
                              int mode, int track_mode, int B, int C, int64_t HW, float grad_scale, void* dlogits,
                              void* pred, int pred_bytes, float* loss_px, void* workspace, size_t workspace_bytes,
                              float* loss_sum, float* track_sum, int32_t* n_correct, void* stream, int force_vec) {
-  SEA_CHECK_ARG(logits && y && workspace && loss_sum && track_sum && n_correct);
+  SEA_CHECK_ARG(logits && y && workspace);
+  // loss_sum == track_sum == n_correct == NULL: leave the per-block records in the workspace for
+  // sea_apgd_track (one launch less in the APGD loop)
+  const bool deferred = !loss_sum && !track_sum && !n_correct;
+  SEA_CHECK_ARG(deferred || (loss_sum && track_sum && n_correct));
   SEA_CHECK_ARG(B > 0 && B <= 65535 && C > 0 && HW > 0);
   SEA_CHECK_ARG(mode >= 0 && mode <= 3 && track_mode >= 0 && track_mode <= 3);
   SEA_CHECK_ARG(!((mode == SEA_MODE_MASK_CE_BAL || track_mode == SEA_MODE_MASK_CE_BAL) && w == nullptr));
@@ -663,8 +678,9 @@ static int loss_fwd_bwd_impl(const void* logits, int dtype, int layout, const vo
     default: return SEA_ERR_ARG;
   }
   if (rc) return rc;
-  hipLaunchKernelGGL(loss_finalize, dim3(B), dim3(256), 0, a.s, (const BlockPartial*)workspace, tiles, loss_sum,
-                     track_sum, n_correct);
+  if (!deferred)
+    hipLaunchKernelGGL(loss_finalize, dim3(B), dim3(256), 0, a.s, (const BlockPartial*)workspace, tiles, loss_sum,
+                       track_sum, n_correct);
   SEA_RETURN_LAST();
 }
 
@@ -674,7 +690,7 @@ using namespace sea;
 
 extern "C" size_t sea_loss_workspace_bytes(int B, int64_t HW) {
   if (B <= 0 || HW <= 0) return 0;
-  return (size_t)B * (size_t)max_tiles(HW) * sizeof(BlockPartial);
+  return ((size_t)B * (size_t)max_tiles(HW) + 1) * sizeof(BlockPartial);
 }
 
 extern "C" int sea_loss_fwd_bwd(const void* logits, int dtype, int layout, const void* y, int y_bytes,

@@ -40,7 +40,7 @@ _SIGS = {
     "sea_class_counts": (_i, [_vp, _i, _vp, _i, _i, _i, _i64, _i, _i, _vp, _vp, _vp, _vp]),
     "sea_confusion": (_i, [_vp, _i, _vp, _i, _i64, _i, _vp, _vp]),
     "sea_apgd_track": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                            _vp, _vp, _vp]),
+                            _vp, _vp, _vp, _vp]),
     "sea_select_copy": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _vp]),
     "sea_count_ignored": (_i, [_vp, _i, _i, _i64, _vp, _vp]),
     "sea_worst_miou_greedy": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
@@ -162,8 +162,10 @@ def loss_workspace(B: int, HW: int, device) -> torch.Tensor:
 
 
 def loss_fwd_bwd(logits, y, weights, mode: int, track_mode: int, grad_scale: float, want_grad: bool = True,
-                 pred=None, loss_px=None, workspace=None, out=None, dlogits=None, force_vec: int = 0):
-    """Run K2.  Returns dict(dlogits, loss_sum, track_sum, n_correct, pred)."""
+                 pred=None, loss_px=None, workspace=None, out=None, dlogits=None, force_vec: int = 0,
+                 defer: bool = False):
+    """Run K2.  Returns dict(dlogits, loss_sum, track_sum, n_correct, pred, workspace).  With ``defer`` the
+    second reduction stage is left to ``apgd_track`` (the sums are then None)."""
     _dev(logits, y, weights, pred, loss_px)
     logits, layout = logits_layout(logits)
     B, Cc, H, W = logits.shape
@@ -173,7 +175,9 @@ def loss_fwd_bwd(logits, y, weights, mode: int, track_mode: int, grad_scale: flo
     dev = logits.device
     if workspace is None:
         workspace = loss_workspace(B, HW, dev)
-    if out is None:
+    if defer:
+        out = (None, None, None)
+    elif out is None:
         out = (torch.empty(B, dtype=torch.float32, device=dev), torch.empty(B, dtype=torch.float32, device=dev),
                torch.empty(B, dtype=torch.int32, device=dev))
     if want_grad and dlogits is None:
@@ -192,7 +196,8 @@ def loss_fwd_bwd(logits, y, weights, mode: int, track_mode: int, grad_scale: flo
         _check(L.sea_loss_fwd_bwd_tuned(*args, force_vec), "sea_loss_fwd_bwd_tuned")
     else:
         _check(L.sea_loss_fwd_bwd(*args), "sea_loss_fwd_bwd")
-    return dict(dlogits=dlogits, loss_sum=out[0], track_sum=out[1], n_correct=out[2], pred=pred)
+    return dict(dlogits=dlogits, loss_sum=out[0], track_sum=out[1], n_correct=out[2], pred=pred,
+                workspace=workspace if defer else None)
 
 
 def loss_fwd_bwd_upsampled(low, y, weights, mode: int, track_mode: int, grad_scale: float, want_grad: bool = True,
@@ -267,7 +272,7 @@ def apgd_track(stats, n_ignored, HW: int, it: int, n_iter: int, check_k: int, ea
                                 _p(n_ignored), st.B, HW, it, n_iter, check_k, int(early_stop), int(init),
                                 _p(st.acc_cnt), _p(st.acc), _p(st.loss_best), _p(st.loss_best_last),
                                 _p(st.reduced_last), _p(st.step), _p(st.loss_steps), _p(st.flags), _p(st.done),
-                                _stream()), "sea_apgd_track")
+                                _p(stats.get("workspace")), _stream()), "sea_apgd_track")
 
 
 def select_copy(flags, x_adv, grad, x_best, grad_best, x_best_adv, pred=None, pred_best=None):

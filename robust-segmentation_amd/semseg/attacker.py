@@ -286,6 +286,7 @@ class ApgdRun:
         self.ws = N.loss_workspace(B, self.HW, device)
         self.gscale = 1.0 / float(self.HW)
         self.dlogits = None
+        self.defer = True      # K7 sums K2's per-block records itself (no finalize launch); off when verbose
         self.ws_low = None
         self.last = None       # K2 outputs of the latest iterate
         self.k2_events = None  # optional list of (start, end) event pairs, one per step (bench.py)
@@ -306,7 +307,7 @@ class ApgdRun:
         else:
             r = N.loss_fwd_bwd(logits.detach(), self.yc, self.w, self.mode, self.tmode, self.gscale,
                                want_grad=want_grad, pred=self.pred, workspace=self.ws, out=self.stats,
-                               dlogits=self.dlogits if want_grad else None)
+                               dlogits=self.dlogits if want_grad else None, defer=self.defer)
         if ev is not None:
             ev[1].record()
             self.k2_events.append(ev)
@@ -380,6 +381,7 @@ def apgd_train(model, x, y, norm, eps, n_iter=10, use_rs=False, loss="ce", verbo
     x_adv = x_adv.clamp_(0.0, 1.0)
 
     run = ApgdRun(model, x, y, eps, n_iter, loss, track_loss, early_stop, num_classes, weights, x_adv)
+    run.defer = not verbose  # the verbose log line reads the per-image sums on the host
     if logger is not None and verbose:
         n_ign = int(run.n_ignored.sum())
         if n_ign > 0:

@@ -132,3 +132,56 @@ def test_no_cpu_fallback(A):
     y = torch.zeros(1, 8, 8, dtype=torch.int64)
     with pytest.raises(_native.SeaNativeError):
         A.apgd_train(net, x, y, "Linf", 4.0 / 255, n_iter=2, loss="mask-ce-avg")
+
+
+def test_apgd_restarts_api(A):
+    """cold API of the reference (attacker.py:574-659): runs, respects the eps-ball, never increases accuracy"""
+    net = TinyConvNet(5, seed=2).cuda()
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(3, 3, 16, 16, generator=g).cuda()
+    with torch.no_grad():
+        y = net(x).max(1)[1]
+    x_adv, _, acc = A.apgd_restarts(net, x, y, norm="Linf", eps=8 / 255, n_iter=5, loss="mask-ce-avg", n_restarts=2,
+                                    track_loss="ce-avg")
+    assert (x_adv - x).abs().max() <= 8 / 255 + 1e-6 and x_adv.min() >= 0 and x_adv.max() <= 1
+    assert (acc <= 1.0).all() and acc.mean() < 1.0
+
+
+def test_val_evaluate_and_metrics_on_device():
+    from oracle import sea_oracle as O
+    from semseg import val as V
+    net = TinyConvNet(7, seed=5).cuda()
+    g = torch.Generator().manual_seed(8)
+    batches = []
+    for _ in range(3):
+        x = torch.rand(2, 3, 24, 20, generator=g)
+        y = torch.randint(0, 7, (2, 24, 20), generator=g)
+        y[torch.rand(y.shape, generator=g) < 0.1] = -1
+        batches.append((x, y))
+    cla_acc, macc, aacc, f1, mf1, ious, miou = V.evaluate(net, batches, "cuda", 7)
+    hist = torch.zeros(7, 7, dtype=torch.int64)
+    with torch.no_grad():
+        for x, y in batches:
+            hist += O.confusion_matrix(net(x.cuda()).max(1)[1].cpu(), y, 7)
+    ref = O.metrics_from_hist(hist)
+    assert miou == ref["miou"] and macc == ref["macc"] and mf1 == ref["mf1"]
+    assert ious == ref["ious"] and cla_acc == ref["acc"] and f1 == ref["f1"]
+    assert float(aacc) == pytest.approx(float(ref["aacc"]))
+
+
+def test_pgd_attack_under_bf16_autocast():
+    """PIR-AT config 4 runs the inner PGD under bf16 autocast: K2 takes the bf16 logits natively"""
+    from semseg.val import Pgd_Attack_1
+    net = TinyConvNet(21, seed=9).cuda()
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(2, 3, 32, 32, generator=g).cuda()
+    with torch.no_grad():
+        y = net(x).max(1)[1]
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        x_adv, logits, _ = Pgd_Attack_1(epsilon=4 / 255, alpha=1e-2, num_iter=3, los="pgd").adv_attack(net, x, y)
+    assert logits.dtype == torch.bfloat16 and x_adv.dtype == torch.float32
+    assert (x_adv - x).abs().max() <= 4 / 255 + 1e-6
+    with torch.no_grad():
+        acc0 = (net(x).max(1)[1] == y).float().mean()
+        acc1 = (net(x_adv).max(1)[1] == y).float().mean()
+    assert acc1 < acc0

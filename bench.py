@@ -141,6 +141,18 @@ def main():
         dt = float(t.item())
 
     k2_ms = sum(a.elapsed_time(b) for a, b in run.k2_events) / max(len(run.k2_events), 1)
+    # measured device-copy ceiling of this GPU (SURVEY 8d asks for it next to the 8 TB/s spec peak)
+    src = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device=device)  # 1 GiB
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+    for a_, b_ in ev:
+        a_.record()
+        dst.copy_(src)
+        b_.record()
+    torch.cuda.synchronize()
+    copy_gbs = 2 * src.numel() * 4 / (min(a_.elapsed_time(b_) for a_, b_ in ev) * 1e-3) / 1e9
+    del src, dst
     algo = k2_algorithmic_bytes(B, C, 512 * 512)
     kname = "loss_upsampled_kernel (K2u)" if run.fused else f"loss_nchw_reg<C={C}> (K2 fused loss fwd+bwd)"
     achieved = algo / (k2_ms * 1e-3) / 1e9
@@ -170,7 +182,8 @@ def main():
             },
             "roofline": {"kernel": kname, "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes": algo, "avg_launch_ms": k2_ms},
+                         "algorithmic_bytes": algo, "avg_launch_ms": k2_ms,
+                         "measured_copy_ceiling_GBps": copy_gbs, "frac_of_copy_ceiling": achieved / copy_gbs},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(C, args.backbone, args.loss, eps)

@@ -158,6 +158,12 @@ def main():
     mult = {"K1": 5, "K6": 5, "K5": 3, "K4": 5, "ref": 2}
     for k, ms in t.items():
         report(k, ms, mult[k.split()[0]] * n)
+    big_src = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device="cuda")
+    big_dst = torch.empty_like(big_src)
+    t = timeit({"ref device copy 1 GiB -> 1 GiB (measured HBM copy ceiling)": lambda: big_dst.copy_(big_src)}, rounds=7)
+    for k, ms in t.items():
+        report(k, ms, 2 * big_src.numel() * 4)
+    del big_src, big_dst
 
     # ---------------- M2 / M1 (model side) ---------------------------------------------------------------
     import torch.nn.functional as F

@@ -23,38 +23,33 @@ __global__ __launch_bounds__(256) void apgd_track_kernel(
     float* __restrict__ loss_steps, uint8_t* __restrict__ flags, int32_t* __restrict__ done,
     const LossRecord* __restrict__ records) {
   __shared__ int s_any_nonzero;
-  __shared__ double s_t[256];
-  __shared__ int s_n[256];
   __shared__ float s_track[1024];
   __shared__ int s_corr[1024];
   if (threadIdx.x == 0) s_any_nonzero = 0;
   // Deferred K2 reduction: sum the per-block records of every image here (fixed order, double), so the
   // loop needs no separate finalize launch.  records[0] is the header {.,., tiles, images}.
   if (records != nullptr) {
+    // one wave per image (4 images in flight): lanes stride over the records, shuffle-reduce in double;
+    // the order is fixed, so the sums are reproducible
     const int tiles = records[0].n_correct;
-    for (int b = 0; b < B && b < 1024; ++b) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int b = wave; b < B && b < 1024; b += 4) {
       double t = 0.0;
       int n = 0;
-      for (int i = threadIdx.x; i < tiles; i += blockDim.x) {
+      for (int i = lane; i < tiles; i += 64) {
         const LossRecord r = records[1 + (int64_t)b * tiles + i];
         t += (double)r.track;
         n += r.n_correct;
       }
-      s_t[threadIdx.x] = t;
-      s_n[threadIdx.x] = n;
-      __syncthreads();
-      for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) {
-          s_t[threadIdx.x] += s_t[threadIdx.x + o];
-          s_n[threadIdx.x] += s_n[threadIdx.x + o];
-        }
-        __syncthreads();
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        t += __shfl_down(t, o, 64);
+        n += __shfl_down(n, o, 64);
       }
-      if (threadIdx.x == 0) {
-        s_track[b] = (float)s_t[0];
-        s_corr[b] = s_n[0];
+      if (lane == 0) {
+        s_track[b] = (float)t;
+        s_corr[b] = n;
       }
-      __syncthreads();
     }
   }
   __syncthreads();

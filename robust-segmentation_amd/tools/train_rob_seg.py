@@ -104,10 +104,10 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
-    torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     torch.backends.cudnn.benchmark = True
     torch.manual_seed(0)

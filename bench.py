@@ -97,13 +97,16 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+    # SEA_BENCH_BACKEND=gloo lets the multi-rank control flow be exercised on a single-GPU box (ranks then
+    # share device 0); the real thing is "nccl" (= RCCL) with one GPU per rank
+    backend = os.environ.get("SEA_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
+        dist.init_process_group(backend, rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
     torch.backends.cudnn.benchmark = True  # MIOpen find mode: pick the fastest conv algorithms
@@ -137,7 +140,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

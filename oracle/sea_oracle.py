@@ -18,7 +18,7 @@ from __future__ import annotations
 import math
 import random
 import statistics
-from typing import Callable, Optional, Sequence
+from typing import Optional, Sequence
 
 import torch
 

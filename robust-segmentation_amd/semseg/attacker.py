@@ -21,9 +21,7 @@ Only device tensors are accepted: there is no CPU fallback (see semseg/_native.p
 """
 from __future__ import annotations
 
-import math
 from functools import partial
-from typing import Optional
 
 import torch
 
@@ -64,7 +62,8 @@ class _PixelLoss(torch.autograd.Function):
         loss_px = torch.empty(B, H, W, dtype=torch.float32, device=logits.device)
         need_grad = logits.requires_grad
         r = N.loss_fwd_bwd(lg, target.contiguous(), weights, mode, mode, 1.0, want_grad=need_grad, loss_px=loss_px)
-        ctx.save_for_backward(r["dlogits"]) if need_grad else None
+        if need_grad:
+            ctx.save_for_backward(r["dlogits"])
         ctx.has_grad = need_grad
         return loss_px
 

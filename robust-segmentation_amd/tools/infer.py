@@ -197,7 +197,6 @@ def main(argv=None):
                      "loss-wise_miou": indiv_mious}
         addendum = "SEA_" + modelName
         torch.save(save_dict, os.path.join(cfg["SAVE_DIR"], f"worse_{addendum}_{test_cfg['NAME']}_{args.eps}.pt"))
-        n_steps = 3 * (args.n_iter + 3)
         summary = {"model": modelName, "n_images": n_img, "world": world, "eps": args.eps, "clean": clean_stats,
                    "worst_Acc": worst, "worst_Acc_indiv": indiv.tolist(), "final_miou": miou,
                    "loss-wise_miou": indiv_mious, "attack_seconds": t_attack,

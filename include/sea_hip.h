@@ -222,6 +222,34 @@ int sea_upsample_bilinear_fwd(const float* x, float* y, int64_t planes, int h, i
                               void* stream);
 int sea_upsample_bilinear_bwd(const float* gy, float* gx, int64_t planes, int h, int w, int H, int W,
                               void* stream);
+/* channels_last variants (x/gx: (B,h,w,C), y/gy: (B,H,W,C), C % 4 == 0, 16-byte aligned): lanes run
+ * along C, so the head's NHWC tensors (what MIOpen's igemm convolutions return) need no layout copy.
+ * y / gy may be a channel slice of a wider NHWC tensor (the FPN / PSP concatenation buffers,
+ * uperforseg.py:171-177, 255-262): *_pixel_stride = floats between consecutive pixels (>= C, % 4 == 0),
+ * batch stride = H*W*pixel_stride.  The up-sampled maps are then written straight into the buffer
+ * torch.cat would have produced, and the gradient is gathered straight out of its gradient.
+ * residual (NULL or dense (B,H,W,C)): y = residual + up(x), the FPN top-down add (uperforseg.py:243-250). */
+int sea_upsample_bilinear_nhwc_fwd(const float* x, const float* residual, float* y, int B, int C, int h,
+                                   int w, int H, int W, int64_t y_pixel_stride, void* stream);
+int sea_upsample_bilinear_nhwc_bwd(const float* gy, float* gx, int B, int C, int h, int w, int H, int W,
+                                   int64_t gy_pixel_stride, void* stream);
+
+/* M4  (model side) Winograd F(m x m, 3 x 3) transforms, m = 2 or 4, for the 3x3 / stride 1 / pad 1
+ * convolutions of the UperNet head (uperforseg.py:200-215 fpn_convs, 255-262 fpn_bottleneck), fp32 NHWC.
+ * The convolution becomes  y = OUT( bmm( IN(x), FIL(w) ) ): the (m+2)^2 GEMMs in the middle are a plain
+ * strided-batched fp32 GEMM (hipBLASLt); these three entry points are the HBM-bound transforms.
+ *   T = sea_wino_tiles(B, H, W, m) = B * ceil(H/m) * ceil(W/m),  A = m + 2
+ *   sea_wino_input_transform :  x (B,H,W,C) -> V (A*A, T, C)
+ *   sea_wino_filter_transform:  w (Cout,Cin,3,3) -> U (A*A, Cin, Cout)             (flip = 0, forward)
+ *                               w -> U (A*A, Cout, Cin) of the 180-degree rotated filters (flip = 1: the
+ *                               convolution that yields the input gradient from the output gradient)
+ *   sea_wino_output_transform:  M (A*A, T, C) (+ bias[C] or NULL) -> y (B,H,W,C)
+ * C % 4 == 0, 16-byte aligned pointers. */
+int64_t sea_wino_tiles(int B, int H, int W, int m);
+int sea_wino_input_transform(const float* x, float* V, int B, int C, int H, int W, int m, void* stream);
+int sea_wino_filter_transform(const float* w, float* U, int Cout, int Cin, int m, int flip, void* stream);
+int sea_wino_output_transform(const float* M, const float* bias, float* y, int B, int C, int H, int W, int m,
+                              void* stream);
 
 /* M3  (model side) NCHW <-> NHWC layout changes of the ConvNeXt block through LDS-tiled transposes,
  * fused with the per-channel layer scale and the residual add (convnext_orig.py:75-86: the two

@@ -33,6 +33,7 @@ SOURCES = [
     ("dwconv_kernels.hip", []),
     ("upsample_kernels.hip", []),
     ("transpose_kernels.hip", ["-ffp-contract=off"]),
+    ("wino_kernels.hip", []),
     ("greedy_host.cpp", ["-ffp-contract=off"]),
     ("api_misc.cpp", []),
 ]

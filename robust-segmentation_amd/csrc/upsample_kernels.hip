@@ -169,6 +169,81 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
   }
 }
 
+// ---- channels_last variants: x (B,h,w,C), y (B,H,W,C), C % 4 == 0 ------------------------------------------
+// Lanes run along the channel dimension (16-byte accesses, perfectly coalesced); no LDS.  The UperNet head
+// is channels_last end to end on ROCm (MIOpen's NHWC igemm kernels return that layout), so these variants
+// remove the layout copies around every up-sampling.
+__global__ __launch_bounds__(256) void upsample_nhwc_fwd_kernel(const float4* __restrict__ x,
+                                                                const float4* __restrict__ res, float4* __restrict__ y,
+                                                                int CG, int h, int w, int H, int W, float rh, float rw,
+                                                                int64_t total, int64_t ypg) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % CG);
+    int64_t p = i / CG;
+    const int64_t opix = p;
+    const int X = (int)(p % W);
+    p /= W;
+    const int Y = (int)(p % H);
+    const int b = (int)(p / H);
+    const AxisMapU my = axis_map_u(Y, rh, h), mx = axis_map_u(X, rw, w);
+    const float4* xb = x + (int64_t)b * h * w * CG + cg;
+    const float4 v00 = xb[((int64_t)my.i0 * w + mx.i0) * CG], v01 = xb[((int64_t)my.i0 * w + mx.i1) * CG];
+    const float4 v10 = xb[((int64_t)my.i1 * w + mx.i0) * CG], v11 = xb[((int64_t)my.i1 * w + mx.i1) * CG];
+    const float lx = mx.lam, ly = my.lam, ux = 1.f - lx, uy = 1.f - ly;
+    float4 o;
+    o.x = uy * (ux * v00.x + lx * v01.x) + ly * (ux * v10.x + lx * v11.x);
+    o.y = uy * (ux * v00.y + lx * v01.y) + ly * (ux * v10.y + lx * v11.y);
+    o.z = uy * (ux * v00.z + lx * v01.z) + ly * (ux * v10.z + lx * v11.z);
+    o.w = uy * (ux * v00.w + lx * v01.w) + ly * (ux * v10.w + lx * v11.w);
+    if (res) {  // fused top-down add of the FPN: y = residual + up(x), residual dense (B,H,W,C)
+      const float4 r = res[i];
+      o.x += r.x;
+      o.y += r.y;
+      o.z += r.z;
+      o.w += r.w;
+    }
+    y[opix * ypg + cg] = o;
+  }
+}
+
+// gather: one lane = (input pixel, 4 channels); footprint rows/cols from ATen's source-index rule
+__global__ __launch_bounds__(256) void upsample_nhwc_bwd_kernel(const float4* __restrict__ gy, float4* __restrict__ gx,
+                                                                int CG, int h, int w, int H, int W, float rh, float rw,
+                                                                int64_t total, int64_t gpg) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % CG);
+    int64_t p = i / CG;
+    const int xq = (int)(p % w);
+    p /= w;
+    const int yq = (int)(p % h);
+    const int b = (int)(p / h);
+    const int Ylo = first_dst_ge(yq - 1, rh, h, H), Yhi = first_dst_ge(yq + 1, rh, h, H);
+    const int Xlo = first_dst_ge(xq - 1, rw, w, W), Xhi = first_dst_ge(xq + 1, rw, w, W);
+    const float4* gb = gy + (int64_t)b * H * W * gpg + cg;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int Y = Ylo; Y < Yhi; ++Y) {
+      const AxisMapU my = axis_map_u(Y, rh, h);
+      const float wy = ((my.i0 == yq) ? (1.f - my.lam) : 0.f) + ((my.i1 == yq) ? my.lam : 0.f);
+      if (wy == 0.f) continue;
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int X = Xlo; X < Xhi; ++X) {
+        const AxisMapU mx = axis_map_u(X, rw, w);
+        const float wx = ((mx.i0 == xq) ? (1.f - mx.lam) : 0.f) + ((mx.i1 == xq) ? mx.lam : 0.f);
+        const float4 g = gb[((int64_t)Y * W + X) * gpg];
+        r.x = fmaf(wx, g.x, r.x);
+        r.y = fmaf(wx, g.y, r.y);
+        r.z = fmaf(wx, g.z, r.z);
+        r.w = fmaf(wx, g.w, r.w);
+      }
+      acc.x = fmaf(wy, r.x, acc.x);
+      acc.y = fmaf(wy, r.y, acc.y);
+      acc.z = fmaf(wy, r.z, acc.z);
+      acc.w = fmaf(wy, r.w, acc.w);
+    }
+    gx[i] = acc;
+  }
+}
+
 static bool plan_bwd(int h, int w, int H, int W, int* TI, int* RMAX, size_t* lds) {
   const double sh = (double)H / h, sw = (double)W / w;
   const double s = sh > sw ? sh : sw;
@@ -220,5 +295,32 @@ extern "C" int sea_upsample_bilinear_bwd(const float* gy, float* gx, int64_t pla
     hipLaunchKernelGGL(upsample_bwd_kernel, grid, dim3(256), lds, s, gy + p0 * H * W, gx + p0 * h * w, h, w, H, W, rh,
                        rw, TI, RMAX);
   }
+  SEA_RETURN_LAST();
+}
+
+// channels_last: x (B,h,w,C) -> y (B,H,W,C) and the gradient w.r.t. x; C % 4 == 0, 16-byte aligned.
+// residual (nullable, dense (B,H,W,C)) is added to the up-sampled map.  y / gy may be a channel slice of a wider NHWC tensor: *_pixel_stride is the distance in floats between
+// consecutive pixels (>= C, % 4 == 0), so the op can write into / read from a concatenation buffer in place.
+extern "C" int sea_upsample_bilinear_nhwc_fwd(const float* x, const float* residual, float* y, int B, int C, int h, int w,
+                                              int H, int W, int64_t y_pixel_stride, void* stream) {
+  SEA_CHECK_ARG(x && y && B > 0 && C > 0 && (C % 4) == 0 && h > 0 && w > 0 && H >= h && W >= w);
+  SEA_CHECK_ARG(y_pixel_stride >= C && (y_pixel_stride % 4) == 0);
+  SEA_CHECK_ARG(((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)residual)) & 15) == 0);
+  const int64_t total = (int64_t)B * H * W * (C / 4);
+  hipLaunchKernelGGL(upsample_nhwc_fwd_kernel, dim3(grid_for(total, 256 * 2)), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)x, (const float4*)residual, (float4*)y, C / 4, h, w, H, W, (float)h / (float)H, (float)w / (float)W, total,
+                     y_pixel_stride / 4);
+  SEA_RETURN_LAST();
+}
+
+extern "C" int sea_upsample_bilinear_nhwc_bwd(const float* gy, float* gx, int B, int C, int h, int w, int H, int W,
+                                              int64_t gy_pixel_stride, void* stream) {
+  SEA_CHECK_ARG(gy && gx && B > 0 && C > 0 && (C % 4) == 0 && h > 0 && w > 0 && H >= h && W >= w);
+  SEA_CHECK_ARG(gy_pixel_stride >= C && (gy_pixel_stride % 4) == 0);
+  SEA_CHECK_ARG(((((uintptr_t)gy) | ((uintptr_t)gx)) & 15) == 0);
+  const int64_t total = (int64_t)B * h * w * (C / 4);
+  hipLaunchKernelGGL(upsample_nhwc_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)gy, (float4*)gx, C / 4, h, w, H, W, (float)h / (float)H, (float)w / (float)W, total,
+                     gy_pixel_stride / 4);
   SEA_RETURN_LAST();
 }

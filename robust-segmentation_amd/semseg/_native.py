@@ -50,6 +50,12 @@ _SIGS = {
     "sea_nhwc_to_nchw": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _vp]),
     "sea_upsample_bilinear_fwd": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "sea_upsample_bilinear_bwd": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp]),
+    "sea_wino_tiles": (_i64, [_i, _i, _i, _i]),
+    "sea_wino_input_transform": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sea_wino_filter_transform": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "sea_wino_output_transform": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sea_upsample_bilinear_nhwc_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i64, _vp]),
+    "sea_upsample_bilinear_nhwc_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i64, _vp]),
 }
 EXPORTS = tuple(_SIGS)
 
@@ -315,6 +321,94 @@ def upsample_bilinear_backward(gy, in_size):
     gx = torch.empty(B, Cc, h, w, dtype=torch.float32, device=gy.device)
     _check(lib().sea_upsample_bilinear_bwd(_p(gy), _p(gx), B * Cc, h, w, H, W, _stream()), "sea_upsample_bilinear_bwd")
     return gx
+
+
+def _is_cl(t) -> bool:
+    """dense channels_last (and not simultaneously NCHW-contiguous) with C % 4 == 0"""
+    return (t.dim() == 4 and t.shape[1] % 4 == 0 and not t.is_contiguous()
+            and t.is_contiguous(memory_format=torch.channels_last))
+
+
+def cl_pixel_stride(t):
+    """Floats between consecutive pixels if `t` (B,C,H,W) is an NHWC tensor or a channel slice of one
+    (strides (H*W*S, 1, W*S, S) with S >= C, S % 4 == 0, C % 4 == 0, 16-byte aligned), else None."""
+    if t.dim() != 4 or t.dtype != torch.float32:
+        return None
+    B, Cc, H, W = t.shape
+    sb, sc, sh, sw = t.stride()
+    S = sw if W > 1 else (sh if H > 1 else (sb if B > 1 else Cc))
+    ok = (Cc % 4 == 0 and S % 4 == 0 and S >= Cc and (sc == 1 or Cc == 1) and (W == 1 or sw == S)
+          and (H == 1 or sh == W * S) and (B == 1 or sb == H * W * S) and t.data_ptr() % 16 == 0)
+    return S if ok else None
+
+
+def upsample_bilinear_cl(x, size, out=None, residual=None):
+    """Same op on a channels_last (B,C,h,w) tensor; returns a channels_last (B,C,H,W) tensor.  `out` may be a
+    channel slice of a wider channels_last tensor (written in place); `residual` (dense channels_last,
+    (B,C,H,W)) is added to the result."""
+    _dev(x, out, residual)
+    if x.dtype != torch.float32 or cl_pixel_stride(x) != x.shape[1]:
+        raise SeaNativeError("expected a dense channels_last float32 tensor with C % 4 == 0")
+    B, Cc, h, w = x.shape
+    H, W = int(size[0]), int(size[1])
+    if out is None:
+        out = torch.empty(B, Cc, H, W, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    S = cl_pixel_stride(out)
+    if tuple(out.shape) != (B, Cc, H, W) or S is None:
+        raise SeaNativeError("out must be a (B,C,H,W) channels_last tensor or a channel slice of one")
+    if residual is not None and (tuple(residual.shape) != (B, Cc, H, W) or cl_pixel_stride(residual) != Cc):
+        raise SeaNativeError("residual must be a dense channels_last (B,C,H,W) float32 tensor")
+    _check(lib().sea_upsample_bilinear_nhwc_fwd(_p(x), _p(residual), _p(out), B, Cc, h, w, H, W, S, _stream()),
+           "sea_upsample_bilinear_nhwc_fwd")
+    return out
+
+
+def upsample_bilinear_backward_cl(gy, in_size):
+    """Gradient w.r.t. the low-resolution input; gy is channels_last or a channel slice of such a tensor."""
+    _dev(gy)
+    S = cl_pixel_stride(gy)
+    if S is None:
+        raise SeaNativeError("expected a channels_last float32 tensor (or channel slice) with C % 4 == 0")
+    B, Cc, H, W = gy.shape
+    h, w = int(in_size[0]), int(in_size[1])
+    gx = torch.empty(B, Cc, h, w, dtype=torch.float32, device=gy.device, memory_format=torch.channels_last)
+    _check(lib().sea_upsample_bilinear_nhwc_bwd(_p(gy), _p(gx), B, Cc, h, w, H, W, S, _stream()),
+           "sea_upsample_bilinear_nhwc_bwd")
+    return gx
+
+
+# ------------------------------------------------------------------------------------------------ M4
+def wino_filter(weight, m: int, flip: bool):
+    """(Cout,Cin,3,3) -> Winograd-domain filters: (A*A, Cin, Cout), or (A*A, Cout, Cin) rotated when flip."""
+    _dev(weight)
+    Cout, Cin, kh, kw = weight.shape
+    if (kh, kw) != (3, 3):
+        raise SeaNativeError("Winograd path is for 3x3 filters")
+    A = m + 2
+    U = torch.empty((A * A, Cout, Cin) if flip else (A * A, Cin, Cout), dtype=torch.float32, device=weight.device)
+    _check(lib().sea_wino_filter_transform(_p(_f32c(weight)), _p(U), Cout, Cin, m, int(flip), _stream()),
+           "sea_wino_filter_transform")
+    return U
+
+
+def wino_conv3x3_cl(x, U, m: int, bias=None):
+    """3x3 / stride 1 / pad 1 convolution of a dense channels_last (B,Cin,H,W) tensor with Winograd-domain
+    filters U (A*A, Cin, Cout); returns a channels_last (B,Cout,H,W) tensor."""
+    _dev(x, U, bias)
+    B, Cin, H, W = x.shape
+    A2, Ci, Cout = U.shape
+    if cl_pixel_stride(x) != Cin or Ci != Cin or A2 != (m + 2) ** 2 or Cout % 4:
+        raise SeaNativeError("wino_conv3x3_cl: dense channels_last float32 input and matching filters expected")
+    L = lib()
+    T = L.sea_wino_tiles(B, H, W, m)
+    V = torch.empty(A2, T, Cin, dtype=torch.float32, device=x.device)
+    _check(L.sea_wino_input_transform(_p(x), _p(V), B, Cin, H, W, m, _stream()), "sea_wino_input_transform")
+    Mx = torch.bmm(V, U)  # (A*A) independent fp32 GEMMs: hipBLASLt strided-batched
+    del V
+    y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    _check(L.sea_wino_output_transform(_p(Mx), _p(bias), _p(y), B, Cout, H, W, m, _stream()),
+           "sea_wino_output_transform")
+    return y
 
 
 def dwconv7x7_nhwc(x, wt, bias=None, flip: bool = False):

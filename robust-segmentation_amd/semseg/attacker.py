@@ -208,6 +208,25 @@ def compact_labels(y: torch.Tensor, n_cls: int) -> torch.Tensor:
     return y.to(torch.int16).contiguous()
 
 
+class _FrozenParameters:
+    """The attack differentiates w.r.t. the input only (reference line 367: ``torch.autograd.grad(loss, [x])``),
+    so the forward runs with the parameters frozen: autograd keeps no weight-gradient edges and the model's
+    frozen-weight kernels (Winograd-domain filter cache) apply.  ``requires_grad`` flags are restored on exit."""
+
+    def __init__(self, model):
+        plain = isinstance(model, torch.nn.Module) and not isinstance(model, torch.nn.parallel.DistributedDataParallel)
+        self.params = [p for p in model.parameters() if p.requires_grad] if plain else []  # DDP tracks its own flags
+
+    def __enter__(self):
+        for p in self.params:
+            p.requires_grad_(False)
+
+    def __exit__(self, *exc):
+        for p in self.params:
+            p.requires_grad_(True)
+        return False
+
+
 def _forward_logits(model, x_buf, want_grad: bool, lowres: bool = False):
     """Model forward on a leaf alias of the iterate buffer.  With ``lowres`` the model's
     ``forward_lowres`` hook is used: it returns the logits BEFORE the final bilinear upsample, which the
@@ -216,10 +235,10 @@ def _forward_logits(model, x_buf, want_grad: bool, lowres: bool = False):
     fn = model.forward_lowres if lowres else model
     if want_grad:
         x_in.requires_grad_(True)
-        with torch.enable_grad():
+        with torch.enable_grad(), _FrozenParameters(model):
             logits = fn(x_in)
     else:
-        with torch.no_grad():
+        with torch.no_grad(), _FrozenParameters(model):
             logits = fn(x_in)
     if lowres:
         logits = logits[0]

@@ -286,6 +286,44 @@ class ConvNeXt(nn.Module):
         return tuple(feats)
 
 
+# Winograd tile for the head's large 3x3 convolutions: 2 = F(2x2,3x3) (fp32 error on par with a direct
+# convolution, 2.25x fewer multiplications), 4 = F(4x4,3x3) (4x fewer, ~20x larger rounding error), 0 = MIOpen.
+WINOGRAD_TILE = int(os.environ.get("SEA_WINOGRAD", "2"))
+WINOGRAD_MIN_PIXELS = 32 * 32  # below this MIOpen's own kernels win (few tiles per GEMM)
+
+
+class _WinoConv3x3(torch.autograd.Function):
+    """conv2d(x, w, padding=1) for frozen 3x3 filters: libsea_hip Winograd transforms around a hipBLASLt
+    batched GEMM, forward and input gradient (the filters get no gradient: attack-time weights are frozen)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, m, cache):
+        from .. import _native as N
+        key = (weight.data_ptr(), weight._version, m)
+        if cache.get("key") != key:
+            cache.clear()
+            cache.update(key=key, fwd=N.wino_filter(weight.contiguous(), m, False), bwd=None)
+        ctx.cache, ctx.m, ctx.weight = cache, m, weight
+        return N.wino_conv3x3_cl(_dense_cl(x), cache["fwd"], m, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .. import _native as N
+        cache = ctx.cache
+        if cache.get("bwd") is None:
+            cache["bwd"] = N.wino_filter(ctx.weight.contiguous(), ctx.m, True)
+        return N.wino_conv3x3_cl(_dense_cl(gy), cache["bwd"], ctx.m), None, None, None, None
+
+
+def _wino_ok(conv, x):
+    return (WINOGRAD_TILE in (2, 4) and x.is_cuda and x.dtype == torch.float32 and conv.kernel_size == (3, 3)
+            and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
+            and conv.padding_mode == "zeros" and not conv.weight.requires_grad
+            and (conv.bias is None or not conv.bias.requires_grad) and conv.in_channels % 4 == 0
+            and conv.out_channels % 4 == 0 and x.shape[2] * x.shape[3] >= WINOGRAD_MIN_PIXELS
+            and not torch.is_autocast_enabled())
+
+
 class ConvModule(nn.Module):
     """bias-free conv + BatchNorm + ReLU (uperforseg.py:119-146)."""
 
@@ -296,25 +334,38 @@ class ConvModule(nn.Module):
         self.activation = nn.ReLU()
 
     def forward(self, x):
-        return self.activation(self.batch_norm(self.conv(x)))
+        if _wino_ok(self.conv, x):
+            if not hasattr(self, "_wino_cache"):
+                object.__setattr__(self, "_wino_cache", {})
+            y = _WinoConv3x3.apply(x, self.conv.weight, self.conv.bias, WINOGRAD_TILE, self._wino_cache)
+        else:
+            y = self.conv(x)
+        return self.activation(self.batch_norm(y))
 
 
 class _UpsampleBilinear(torch.autograd.Function):
     """Bilinear up-sampling through libsea_hip M2 (forward: one streaming write; backward: deterministic
-    gather)."""
+    gather).  Channels_last inputs (what the head's MIOpen convolutions hand over) stay channels_last: the
+    NHWC kernels run lanes along C, so no layout copy surrounds the op."""
 
     @staticmethod
     def forward(ctx, x, size):
         from .. import _native as N
         ctx.in_size = tuple(x.shape[2:])
+        ctx.cl = USE_HIP_UPSAMPLE_NHWC and N._is_cl(x)
+        if ctx.cl:
+            return N.upsample_bilinear_cl(x, size)
         return N.upsample_bilinear(x.contiguous(), size)
 
     @staticmethod
     def backward(ctx, gy):
         from .. import _native as N
+        if ctx.cl:
+            return N.upsample_bilinear_backward_cl(gy.contiguous(memory_format=torch.channels_last), ctx.in_size), None
         return N.upsample_bilinear_backward(gy.contiguous(), ctx.in_size), None
 
 
+USE_HIP_UPSAMPLE_NHWC = True
 USE_HIP_UPSAMPLE = True
 
 
@@ -324,6 +375,94 @@ def _up(x, size):
             and size[1] >= x.shape[3]):
         return _UpsampleBilinear.apply(x, size)
     return F.interpolate(x, size=size, mode="bilinear", align_corners=False)
+
+
+_CL = torch.channels_last
+
+
+def _dense_cl(t):
+    from .. import _native as N
+    return t if N.cl_pixel_stride(t) == t.shape[1] else t.contiguous(memory_format=_CL)
+
+
+class _UpAddCL(torch.autograd.Function):
+    """res + up(x) in one pass over channels_last tensors (the FPN top-down add)."""
+
+    @staticmethod
+    def forward(ctx, x, res):
+        from .. import _native as N
+        ctx.in_size = tuple(x.shape[2:])
+        return N.upsample_bilinear_cl(_dense_cl(x), res.shape[2:], residual=_dense_cl(res))
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .. import _native as N
+        g = gy if N.cl_pixel_stride(gy) is not None else gy.contiguous(memory_format=_CL)
+        gx = N.upsample_bilinear_backward_cl(g, ctx.in_size) if ctx.needs_input_grad[0] else None
+        return gx, gy
+
+
+class _UpCatCL(torch.autograd.Function):
+    """torch.cat([up(t) for t in ts], 1) for channels_last tensors without materialising the up-sampled maps:
+    each one is written straight into its channel slice of the concatenation buffer, and the backward
+    gathers each gradient straight out of the matching slice of the buffer's gradient."""
+
+    @staticmethod
+    def forward(ctx, size, *ts):
+        from .. import _native as N
+        B, (H, W) = ts[0].shape[0], size
+        buf = torch.empty(B, sum(t.shape[1] for t in ts), H, W, dtype=torch.float32, device=ts[0].device,
+                          memory_format=_CL)
+        off = 0
+        for t in ts:
+            sl = buf[:, off:off + t.shape[1]]
+            if tuple(t.shape[2:]) == (H, W):
+                sl.copy_(t)
+            else:
+                N.upsample_bilinear_cl(_dense_cl(t), size, out=sl)
+            off += t.shape[1]
+        ctx.shapes = [tuple(t.shape) for t in ts]
+        return buf
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import _native as N
+        if N.cl_pixel_stride(g) != g.shape[1]:
+            g = g.contiguous(memory_format=_CL)
+        grads, off = [None], 0
+        for i, shp in enumerate(ctx.shapes):
+            sl = g[:, off:off + shp[1]]
+            off += shp[1]
+            if not ctx.needs_input_grad[i + 1]:
+                grads.append(None)
+            elif shp[2:] == tuple(g.shape[2:]):
+                grads.append(sl)
+            else:
+                grads.append(N.upsample_bilinear_backward_cl(sl, shp[2:]))
+        return tuple(grads)
+
+
+def _cl_fusable(ts, size):
+    from .. import _native as N
+    return (USE_HIP_UPSAMPLE and USE_HIP_UPSAMPLE_NHWC and N._is_cl(ts[0])
+            and all(t.is_cuda and t.dtype == torch.float32 and t.shape[1] % 4 == 0 and t.shape[2] <= size[0]
+                    and t.shape[3] <= size[1] for t in ts))
+
+
+def _up_add(x, res):
+    """res + bilinear_up(x -> res's size)"""
+    size = tuple(int(v) for v in res.shape[2:])
+    if _cl_fusable([res, x], size):
+        return _UpAddCL.apply(x, res)
+    return res + _up(x, size)
+
+
+def _up_cat(ts, size):
+    """torch.cat([bilinear_up(t -> size) for t in ts], dim=1) (tensors already at `size` are copied)"""
+    size = tuple(int(v) for v in size)
+    if _cl_fusable(ts, size):
+        return _UpCatCL.apply(size, *ts)
+    return torch.cat([t if tuple(t.shape[2:]) == size else _up(t, size) for t in ts], dim=1)
 
 
 class PyramidPooling(nn.Module):
@@ -338,12 +477,12 @@ class PyramidPooling(nn.Module):
             self.add_module(str(i), blk)
         self.n = len(scales)
 
+    def pooled(self, x):
+        """the pooled + projected maps at their own (1, 2, 3, 6) resolutions"""
+        return [getattr(getattr(self, str(i)), "1")(getattr(getattr(self, str(i)), "0")(x)) for i in range(self.n)]
+
     def forward(self, x):
-        outs = []
-        for i in range(self.n):
-            blk = getattr(self, str(i))
-            outs.append(_up(getattr(blk, "1")(getattr(blk, "0")(x)), x.shape[2:]))
-        return outs
+        return [_up(p, x.shape[2:]) for p in self.pooled(x)]
 
 
 class UperNetHead(nn.Module):
@@ -363,12 +502,11 @@ class UperNetHead(nn.Module):
     def forward(self, feats):
         top = feats[-1]
         lat = [conv(feats[i]) for i, conv in enumerate(self.lateral_convs)]
-        lat.append(self.bottleneck(torch.cat([top] + self.psp_modules(top), dim=1)))
+        lat.append(self.bottleneck(_up_cat([top] + self.psp_modules.pooled(top), top.shape[2:])))
         for i in range(len(lat) - 1, 0, -1):
-            lat[i - 1] = lat[i - 1] + _up(lat[i], lat[i - 1].shape[2:])
+            lat[i - 1] = _up_add(lat[i], lat[i - 1])
         outs = [self.fpn_convs[i](lat[i]) for i in range(len(lat) - 1)] + [lat[-1]]
-        outs = [outs[0]] + [_up(o, outs[0].shape[2:]) for o in outs[1:]]
-        return self.classifier(self.fpn_bottleneck(torch.cat(outs, dim=1)))
+        return self.classifier(self.fpn_bottleneck(_up_cat(outs, outs[0].shape[2:])))
 
 
 class UperNetFCNHead(nn.Module):
@@ -414,10 +552,10 @@ class UperNetForSemanticSegmentation(nn.Module):
 
     def forward(self, input, lbl=None):
         feats = self.backbone(input)
-        logits = _up(self.decode_head(feats), input.shape[2:])
+        logits = _up(self.decode_head(feats).contiguous(), input.shape[2:])  # NCHW logits for K2
         loss = None
         if lbl is not None:
-            aux = _up(self.auxiliary_head(feats), input.shape[2:])
+            aux = _up(self.auxiliary_head(feats).contiguous(), input.shape[2:])
             loss = F.cross_entropy(logits, lbl, ignore_index=-1) + 0.4 * F.cross_entropy(aux, lbl, ignore_index=-1)
         if self.training:
             return loss, logits

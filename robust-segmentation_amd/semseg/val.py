@@ -11,6 +11,7 @@ from __future__ import annotations
 import torch
 
 from . import _native as N
+from .attacker import _FrozenParameters
 from .metrics import Metrics
 
 __all__ = ["Pgd_Attack", "Pgd_Attack_1", "evaluate", "losses"]
@@ -26,7 +27,7 @@ def _labels(y):
 def _fwd_grad(model, x_in, y, mode, scale, ws, out, dlogits):
     """logits = model(x_in); returns (input gradient of sum of the loss, K2 stats, logits)."""
     x_in = x_in.detach().requires_grad_(True)
-    with torch.enable_grad():
+    with torch.enable_grad(), _FrozenParameters(model):  # gradient w.r.t. the input only (val.py:150, 201)
         logits = model(x_in)
     r = N.loss_fwd_bwd(logits.detach(), y, None, mode, mode, scale, want_grad=True, workspace=ws, out=out,
                        dlogits=dlogits)

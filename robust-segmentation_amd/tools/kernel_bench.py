@@ -175,6 +175,13 @@ def main():
             f"M2 upsample bwd {Cc}ch {hl}->{Hh}": lambda: N.upsample_bilinear_backward(gy, (hl, hl)),
             f"ATen upsample fwd {Cc}ch {hl}->{Hh}": lambda: F.interpolate(xin, size=(Hh, Hh), mode="bilinear", align_corners=False),
         }, rounds=7)
+        if Cc % 4 == 0:
+            xcl = xin.contiguous(memory_format=torch.channels_last)
+            gcl = gy.contiguous(memory_format=torch.channels_last)
+            t.update(timeit({
+                f"M2 upsample NHWC fwd {Cc}ch {hl}->{Hh}": lambda: N.upsample_bilinear_cl(xcl, (Hh, Hh)),
+                f"M2 upsample NHWC bwd {Cc}ch {hl}->{Hh}": lambda: N.upsample_bilinear_backward_cl(gcl, (hl, hl)),
+            }, rounds=7))
         for k, ms in t.items():
             report(k, ms, 4 * (xin.numel() + gy.numel()))
     for Cc, hw in ((96, 128), (192, 64), (384, 32), (768, 16)):

@@ -49,10 +49,23 @@ def test_config1_oracle_matches_reference_on_cpu():
 
 
 @pytest.mark.gpu
-def test_config1_device_path_matches_reference():
+@pytest.mark.parametrize("tile", [2, 4, 0])
+def test_config1_device_path_matches_reference(tile):
+    """tile: Winograd F(tile x tile, 3x3) for the head's 3x3 convolutions (0 = MIOpen's direct kernels)."""
     from semseg import attacker as A
+    from semseg.models import convnext_upernet as M
     g, model, x, y, w, noises = _setup()
     model = model.cuda()
+    old_tile, M.WINOGRAD_TILE = M.WINOGRAD_TILE, tile
+    try:
+        _run_config1(A, g, model, x, y, w, noises)
+    finally:
+        M.WINOGRAD_TILE = old_tile
+        A.FUSE_UPSAMPLE = "auto"
+    assert all(p.requires_grad for p in model.parameters())  # the attack restores the flags it froze
+
+
+def _run_config1(A, g, model, x, y, w, noises):
     for fuse in (False, True):
         A.FUSE_UPSAMPLE = fuse
         xa, _, acc = A.apgd_largereps(model, x.cuda(), y.cuda(), w.cuda(), norm="Linf", eps=EPS, n_iter=5,
@@ -66,4 +79,3 @@ def test_config1_device_path_matches_reference():
             pa = model(xa).max(1)[1]
         m_acc, a_acc, m_iou = A.compute_iou_acc(pa, y.cuda(), 21)
         assert abs(a_acc.item() - g["adv_aacc"]) <= 5e-3 and abs(m_iou.item() - g["adv_miou"]) <= 1e-2
-    A.FUSE_UPSAMPLE = "auto"

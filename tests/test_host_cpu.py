@@ -26,7 +26,7 @@ def native():
 
 def test_library_exports_every_declared_symbol(native):
     header = open(os.path.join(ROOT, "include", "sea_hip.h")).read()
-    declared = set(re.findall(r"^\s*(?:int|size_t|const char\*)\s+(sea_\w+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|int64_t|size_t|const char\*)\s+(sea_\w+)\s*\(", header, flags=re.M))
     assert declared, "no declarations parsed"
     out = subprocess.run(["nm", "-D", "--defined-only", native.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = set(re.findall(r" T (sea_\w+)", out))

@@ -412,22 +412,170 @@ def test_upsample_bilinear_forward_backward(N, case):
     assert torch.equal(gx, N.upsample_bilinear_backward(dev(gy), (h, w)))  # deterministic gather
 
 
+@pytest.mark.parametrize("case", [(2, 8, 16, 16, 32, 32), (1, 4, 32, 32, 128, 128), (2, 12, 16, 16, 128, 128),
+                                  (1, 4, 1, 1, 16, 16), (1, 8, 3, 3, 16, 16), (2, 4, 6, 6, 16, 16),
+                                  (1, 8, 30, 30, 119, 119), (1, 4, 13, 11, 50, 45), (1, 4, 9, 7, 9, 7),
+                                  (2, 512, 4, 4, 8, 8)])
+def test_upsample_bilinear_channels_last(N, case):
+    """The NHWC kernels must agree with the NCHW ones (same arithmetic) and with ATen."""
+    import torch.nn.functional as F
+    B, C, h, w, H, W = case
+    g = torch.Generator().manual_seed(h * 100 + H + 1)
+    x = torch.randn(B, C, h, w, generator=g)
+    gy = torch.randn(B, C, H, W, generator=g)
+    xd = x.double().requires_grad_(True)
+    ref = F.interpolate(xd, size=(H, W), mode="bilinear", align_corners=False)
+    (gx_ref,) = torch.autograd.grad(ref, xd, gy.double())
+    xc = dev(x).contiguous(memory_format=torch.channels_last)
+    gc = dev(gy).contiguous(memory_format=torch.channels_last)
+    y = N.upsample_bilinear_cl(xc, (H, W))
+    assert y.is_contiguous(memory_format=torch.channels_last) and y.shape == (B, C, H, W)
+    ref32 = F.interpolate(x, size=(H, W), mode="bilinear", align_corners=False)
+    torch.testing.assert_close(y.cpu(), ref32, rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(y, N.upsample_bilinear(dev(x), (H, W)), rtol=1e-6, atol=1e-6)
+    gx = N.upsample_bilinear_backward_cl(gc, (h, w))
+    assert gx.is_contiguous(memory_format=torch.channels_last) and gx.shape == (B, C, h, w)
+    torch.testing.assert_close(gx.cpu().double(), gx_ref, rtol=1e-5, atol=1e-3)
+    assert torch.equal(gx, N.upsample_bilinear_backward_cl(gc, (h, w)))
+    if w > 1:
+        with pytest.raises(N.SeaNativeError):
+            N.upsample_bilinear_cl(dev(x), (H, W))  # NCHW tensor refused by the NHWC entry point
+    # in-place into / out of a channel slice of a wider NHWC buffer, with the fused residual add
+    wide = torch.full((B, C + 8, H, W), -7.0, device="cuda").contiguous(memory_format=torch.channels_last)
+    res = dev(torch.randn(B, C, H, W, generator=g)).contiguous(memory_format=torch.channels_last)
+    N.upsample_bilinear_cl(xc, (H, W), out=wide[:, 4:4 + C], residual=res)
+    torch.testing.assert_close(wide[:, 4:4 + C], y + res, rtol=1e-6, atol=1e-6)
+    assert (wide[:, :4] == -7).all() and (wide[:, 4 + C:] == -7).all()
+    gwide = torch.zeros(B, C + 8, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+    gwide[:, 4:4 + C] = gc
+    assert torch.equal(N.upsample_bilinear_backward_cl(gwide[:, 4:4 + C], (h, w)), gx)
+
+
+def test_upernet_head_fused_up_cat_and_up_add(N):
+    """_up_cat / _up_add (NHWC, in-place slices) against torch.cat / + of ATen up-samplings, values and grads."""
+    import torch.nn.functional as F
+    from semseg.models import convnext_upernet as M
+    g = torch.Generator().manual_seed(3)
+    cl = torch.channels_last
+    ts = [torch.randn(2, 8, 24, 20, generator=g), torch.randn(2, 12, 12, 10, generator=g),
+          torch.randn(2, 4, 1, 1, generator=g), torch.randn(2, 8, 5, 7, generator=g)]
+    res0 = torch.randn(2, 12, 24, 20, generator=g)
+
+    def run(fused):
+        M.USE_HIP_UPSAMPLE_NHWC = fused
+        xs = [dev(t).contiguous(memory_format=cl).requires_grad_(True) for t in ts]
+        res = dev(res0).contiguous(memory_format=cl).requires_grad_(True)
+        cat = M._up_cat(xs, (24, 20))
+        add = M._up_add(xs[1], res)
+        loss = (cat * cat).sum() + (add * add * 0.5).sum()
+        return cat.detach(), add.detach(), torch.autograd.grad(loss, xs + [res])
+
+    try:
+        c1, a1, g1 = run(True)
+        c0, a0, g0 = run(False)
+    finally:
+        M.USE_HIP_UPSAMPLE_NHWC = True
+    assert c1.is_contiguous(memory_format=cl)
+    ref = torch.cat([ts[0]] + [F.interpolate(t, size=(24, 20), mode="bilinear", align_corners=False) for t in ts[1:]], 1)
+    torch.testing.assert_close(c1.cpu(), ref, rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(c1, c0, rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(a1, a0, rtol=1e-5, atol=2e-5)
+    for u, v in zip(g1, g0):
+        torch.testing.assert_close(u, v, rtol=1e-4, atol=1e-4)
+
+
 def test_upernet_head_with_and_without_hip_upsample(N):
     from semseg.models import convnext_upernet as M
     torch.manual_seed(0)
     model = M.UperNetForSemanticSegmentation("ConvNeXt-T_CVST", 21, None).cuda().eval()
     x = torch.rand(1, 3, 96, 128, device="cuda")
     outs = []
-    for flag in (True, False):
-        M.USE_HIP_UPSAMPLE = flag
+    for flag, nhwc in ((True, True), (True, False), (False, False)):
+        M.USE_HIP_UPSAMPLE, M.USE_HIP_UPSAMPLE_NHWC = flag, nhwc
         xi = x.clone().requires_grad_(True)
         y = model(xi)
         (gx,) = torch.autograd.grad(y, xi, torch.ones_like(y))
         outs.append((y.detach(), gx))
-    M.USE_HIP_UPSAMPLE = True
-    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-4, atol=1e-4)
-    gmax = outs[1][1].abs().max().item()
-    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-3, atol=1e-3 * gmax)  # ATen's backward sums with atomics
+    M.USE_HIP_UPSAMPLE = M.USE_HIP_UPSAMPLE_NHWC = True
+    gmax = outs[2][1].abs().max().item()
+    for k in (0, 1):
+        assert outs[k][0].is_contiguous()  # NCHW logits for K2
+        torch.testing.assert_close(outs[k][0], outs[2][0], rtol=1e-4, atol=1e-4)
+        # ATen's backward sums with atomics, and last-bit differences flip a few ReLU gates: compare in norm
+        assert (outs[k][1] - outs[2][1]).norm() <= 2e-3 * outs[2][1].norm()
+        assert ((outs[k][1] - outs[2][1]).abs() > 1e-3 * gmax).float().mean() < 0.01
+
+
+# ------------------------------------------------------------------------------------------------ M4
+@pytest.mark.parametrize("m", [2, 4])
+@pytest.mark.parametrize("case", [(2, 8, 12, 16, 16), (1, 64, 32, 33, 31), (2, 4, 4, 5, 7), (1, 16, 8, 1, 1),
+                                  (1, 256, 64, 64, 64)])
+def test_winograd_conv3x3_forward_and_input_gradient(N, m, case):
+    """Winograd transforms + batched GEMM against conv2d in float64: values, bias, ragged tiles, and the
+    input-gradient convolution (rotated filters)."""
+    import torch.nn.functional as F
+    B, Cin, Cout, H, W = case
+    g = torch.Generator().manual_seed(Cin * 7 + H)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)
+    bias = torch.randn(Cout, generator=g)
+    gy = torch.randn(B, Cout, H, W, generator=g)
+    xd = x.double().requires_grad_(True)
+    ref = F.conv2d(xd, w.double(), bias.double(), padding=1)
+    (gx_ref,) = torch.autograd.grad(ref, xd, gy.double())
+    cl = torch.channels_last
+    tol = 2e-5 if m == 2 else 3e-4  # F(4x4,3x3) amplifies fp32 rounding ~20x (documented in DESIGN.md)
+    U = N.wino_filter(dev(w), m, False)
+    y = N.wino_conv3x3_cl(dev(x).contiguous(memory_format=cl), U, m, dev(bias))
+    assert y.shape == (B, Cout, H, W) and y.is_contiguous(memory_format=cl)
+    torch.testing.assert_close(y.cpu().double(), ref.detach(), rtol=tol, atol=tol)
+    Ub = N.wino_filter(dev(w), m, True)
+    gx = N.wino_conv3x3_cl(dev(gy).contiguous(memory_format=cl), Ub, m)
+    torch.testing.assert_close(gx.cpu().double(), gx_ref, rtol=tol, atol=tol)
+    # deterministic
+    assert torch.equal(y, N.wino_conv3x3_cl(dev(x).contiguous(memory_format=cl), U, m, dev(bias)))
+    with pytest.raises(N.SeaNativeError):
+        N.wino_conv3x3_cl(dev(x).contiguous() if W > 1 else dev(x)[:, :, :, :0], U, m)
+
+
+def test_convmodule_winograd_matches_miopen(N):
+    from semseg.models import convnext_upernet as M
+    torch.manual_seed(1)
+    mod = M.ConvModule(64, 32, 3, padding=1).cuda().eval()
+    mod.batch_norm.running_mean.normal_()
+    mod.batch_norm.running_var.uniform_(0.5, 2.0)
+    for p in mod.parameters():
+        p.requires_grad_(False)
+    x = torch.randn(2, 64, 40, 36, device="cuda").contiguous(memory_format=torch.channels_last)
+    outs = []
+    try:
+        for tile in (2, 4, 0):
+            M.WINOGRAD_TILE = tile
+            xi = x.clone().requires_grad_(True)
+            y = mod(xi)
+            (gx,) = torch.autograd.grad((y * y).sum(), xi)
+            outs.append((y.detach(), gx))
+    finally:
+        M.WINOGRAD_TILE = 2
+    for k, tol in ((0, 2e-5), (1, 3e-4)):
+        torch.testing.assert_close(outs[k][0], outs[2][0], rtol=tol, atol=tol)
+        torch.testing.assert_close(outs[k][1], outs[2][1], rtol=tol * 10, atol=tol * 10)
+    # weights that require grad (PIR-AT training) stay on the MIOpen path
+    for p in mod.parameters():
+        p.requires_grad_(True)
+    assert not M._wino_ok(mod.conv, x)
+    # in-place weight updates invalidate the cached Winograd-domain filters
+    for p in mod.parameters():
+        p.requires_grad_(False)
+    y0 = mod(x)
+    mod.conv.weight.mul_(2.0)
+    y1 = mod(x)
+    M.WINOGRAD_TILE = 0
+    try:
+        torch.testing.assert_close(y1, mod(x), rtol=2e-5, atol=2e-5)
+    finally:
+        M.WINOGRAD_TILE = 2
+    assert not torch.equal(y0, y1)
 
 
 # ------------------------------------------------------------------------------------------------ M3

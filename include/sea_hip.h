@@ -239,17 +239,32 @@ int sea_upsample_bilinear_nhwc_bwd(const float* gy, float* gx, int B, int C, int
  * The convolution becomes  y = OUT( bmm( IN(x), FIL(w) ) ): the (m+2)^2 GEMMs in the middle are a plain
  * strided-batched fp32 GEMM (hipBLASLt); these three entry points are the HBM-bound transforms.
  *   T = sea_wino_tiles(B, H, W, m) = B * ceil(H/m) * ceil(W/m),  A = m + 2
- *   sea_wino_input_transform :  x (B,H,W,C) -> V (A*A, T, C)
+ *   sea_wino_input_transform :  x (B,H,W,C) -> V (A*A, T, C); x may be a channel slice of a wider NHWC
+ *                               tensor (x_pixel_stride floats between pixels, >= C, % 4 == 0: the gradient
+ *                               of a concatenation buffer is read in place); with gate (B,H,W,C, dense) the tiles are loaded
+ *                               as  gate > 0 ? x * scale[c] : 0  (scale NULL = 1): the backward of the
+ *                               fused epilogue below, applied to the incoming output gradient
  *   sea_wino_filter_transform:  w (Cout,Cin,3,3) -> U (A*A, Cin, Cout)             (flip = 0, forward)
  *                               w -> U (A*A, Cout, Cin) of the 180-degree rotated filters (flip = 1: the
  *                               convolution that yields the input gradient from the output gradient)
- *   sea_wino_output_transform:  M (A*A, T, C) (+ bias[C] or NULL) -> y (B,H,W,C)
+ *   sea_wino_output_transform:  M (A*A, T, C) -> y (B,H,W,C) = act(scale[c] * conv + bias[c]); scale / bias
+ *                               may be NULL, act = ReLU when relu != 0.  With scale/bias = the folded
+ *                               eval-mode BatchNorm this is the whole ConvModule (uperforseg.py:119-146).
  * C % 4 == 0, 16-byte aligned pointers. */
 int64_t sea_wino_tiles(int B, int H, int W, int m);
-int sea_wino_input_transform(const float* x, float* V, int B, int C, int H, int W, int m, void* stream);
+int sea_wino_input_transform(const float* x, int64_t x_pixel_stride, const float* gate, const float* scale,
+                             float* V, int B, int C, int H, int W, int m, void* stream);
 int sea_wino_filter_transform(const float* w, float* U, int Cout, int Cin, int m, int flip, void* stream);
-int sea_wino_output_transform(const float* M, const float* bias, float* y, int B, int C, int H, int W, int m,
-                              void* stream);
+int sea_wino_output_transform(const float* M, const float* scale, const float* bias, int relu, float* y,
+                              int B, int C, int H, int W, int m, void* stream);
+
+/* M5  (model side) LayerNorm over the last dimension of a (rows, C) fp32 tensor with few channels (ConvNeXt:
+ * C = 48..768, eps 1e-6; convnext_orig.py:19-40), forward and input gradient (w, b frozen).  A row is owned
+ * by 16/32/64 lanes instead of a whole workgroup.  C % 4 == 0, C <= 1024; mean / rstd: (rows) saved statistics. */
+int sea_layernorm_fwd(const float* x, const float* w, const float* b, float* y, float* mean, float* rstd,
+                      int64_t rows, int C, float eps, void* stream);
+int sea_layernorm_bwd(const float* g, const float* x, const float* w, const float* mean, const float* rstd,
+                      float* dx, int64_t rows, int C, void* stream);
 
 /* M3  (model side) NCHW <-> NHWC layout changes of the ConvNeXt block through LDS-tiled transposes,
  * fused with the per-channel layer scale and the residual add (convnext_orig.py:75-86: the two

@@ -34,6 +34,7 @@ SOURCES = [
     ("upsample_kernels.hip", []),
     ("transpose_kernels.hip", ["-ffp-contract=off"]),
     ("wino_kernels.hip", []),
+    ("ln_kernels.hip", []),
     ("greedy_host.cpp", ["-ffp-contract=off"]),
     ("api_misc.cpp", []),
 ]

@@ -83,9 +83,12 @@ __device__ __forceinline__ void vstore(float* p, const float (&v)[VEC]) {
 }
 
 // ---- input transform: V[k][t][c] = (B^T d B)[k], d = the (m+2)^2 patch of tile t (zero outside the image) ----
+// Optional prologue (the backward of a fused scale/shift + ReLU epilogue): d = gate > 0 ? x * scale[c] : 0.
 template <int M, int VEC>
-__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int C,
-                                                         int H, int W, int nTh, int nTw, int64_t T, int64_t total) {
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, const float* __restrict__ gate,
+                                                         const float* __restrict__ scale, float* __restrict__ V, int C,
+                                                         int H, int W, int nTh, int nTw, int64_t T, int64_t total,
+                                                         int64_t xps) {
   constexpr int A = M + 2;
   const int CG = C / VEC;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -96,7 +99,11 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
     const int ty = (int)((t / nTw) % nTh);
     const int b = (int)(t / ((int64_t)nTw * nTh));
     const int y0 = ty * M - 1, x0 = tx * M - 1;
-    const float* xb = x + (int64_t)b * H * W * C + (int64_t)cg * VEC;
+    const int64_t base = (int64_t)b * H * W * C + (int64_t)cg * VEC;
+    const float* xb = x + (int64_t)b * H * W * xps + (int64_t)cg * VEC;  // x may be a channel slice: pixel stride xps
+    float sc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) sc[e] = scale ? scale[cg * VEC + e] : 1.f;
     float d[A][A][VEC];
 #pragma unroll
     for (int i = 0; i < A; ++i) {
@@ -105,7 +112,13 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
       for (int j = 0; j < A; ++j) {
         const int xx = x0 + j;
         if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-          vload<VEC>(xb + ((int64_t)yy * W + xx) * C, d[i][j]);
+          vload<VEC>(xb + ((int64_t)yy * W + xx) * xps, d[i][j]);
+          if (gate) {
+            float gt[VEC];
+            vload<VEC>(gate + base + ((int64_t)yy * W + xx) * C, gt);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) d[i][j][e] = gt[e] > 0.f ? d[i][j][e] * sc[e] : 0.f;
+          }
         } else {
 #pragma unroll
           for (int e = 0; e < VEC; ++e) d[i][j][e] = 0.f;
@@ -137,9 +150,10 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
   }
 }
 
-// ---- output transform: y tile = A^T m A (+ bias), m[k] = M[k][t][c] ---------------------------------------------
+// ---- output transform: y tile = act(scale[c] * (A^T m A) + bias[c]), m[k] = M[k][t][c]; act = ReLU or identity ---
 template <int M, int VEC>
-__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mx, const float* __restrict__ bias,
+__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mx, const float* __restrict__ scale,
+                                                          const float* __restrict__ bias, int relu,
                                                           float* __restrict__ y, int C, int H, int W, int nTh, int nTw,
                                                           int64_t T, int64_t total) {
   constexpr int A = M + 2;
@@ -166,9 +180,12 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
         for (int i = 0; i < A; ++i) axpy<VEC>(wino_at(M, p, i), col[i], tmp[p][j], first);
       }
     }
-    float bv[VEC];
+    float bv[VEC], sv[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) bv[e] = bias ? bias[cg * VEC + e] : 0.f;
+    for (int e = 0; e < VEC; ++e) {
+      bv[e] = bias ? bias[cg * VEC + e] : 0.f;
+      sv[e] = scale ? scale[cg * VEC + e] : 1.f;
+    }
     float* yb = y + (int64_t)b * H * W * C + (int64_t)cg * VEC;
 #pragma unroll
     for (int p = 0; p < M; ++p) {
@@ -181,7 +198,10 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 #pragma unroll
         for (int j = 0; j < A; ++j) axpy<VEC>(wino_at(M, q, j), tmp[p][j], o, first);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) o[e] += bv[e];
+        for (int e = 0; e < VEC; ++e) {
+          o[e] = scale ? fmaf(o[e], sv[e], bv[e]) : o[e] + bv[e];
+          if (relu) o[e] = fmaxf(o[e], 0.f);
+        }
         if (yy < H && xx < W) vstore<VEC>(yb + ((int64_t)yy * W + xx) * C, o);
       }
     }
@@ -246,25 +266,27 @@ extern "C" int64_t sea_wino_tiles(int B, int H, int W, int m) {
   return (int64_t)B * ((H + m - 1) / m) * ((W + m - 1) / m);
 }
 
-extern "C" int sea_wino_input_transform(const float* x, float* V, int B, int C, int H, int W, int m, void* stream) {
+extern "C" int sea_wino_input_transform(const float* x, int64_t x_pixel_stride, const float* gate, const float* scale,
+                                        float* V, int B, int C, int H, int W, int m, void* stream) {
   int nTh, nTw;
   int64_t T;
   SEA_CHECK_ARG(x && V && wino_dims(B, C, H, W, m, 4, &nTh, &nTw, &T));
-  SEA_CHECK_ARG(((((uintptr_t)x) | ((uintptr_t)V)) & 15) == 0);
+  SEA_CHECK_ARG(x_pixel_stride >= C && (x_pixel_stride % 4) == 0);
+  SEA_CHECK_ARG(((((uintptr_t)x) | ((uintptr_t)V) | ((uintptr_t)gate)) & 15) == 0);
   if (m == 2) {
     const int64_t total = T * (C / 4);
-    hipLaunchKernelGGL((wino_input_kernel<2, 4>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, V, C,
-                       H, W, nTh, nTw, T, total);
+    hipLaunchKernelGGL((wino_input_kernel<2, 4>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, gate,
+                       scale, V, C, H, W, nTh, nTw, T, total, x_pixel_stride);
   } else {
     const int64_t total = T * (C / 2);
-    hipLaunchKernelGGL((wino_input_kernel<4, 2>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, V, C,
-                       H, W, nTh, nTw, T, total);
+    hipLaunchKernelGGL((wino_input_kernel<4, 2>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, gate,
+                       scale, V, C, H, W, nTh, nTw, T, total, x_pixel_stride);
   }
   SEA_RETURN_LAST();
 }
 
-extern "C" int sea_wino_output_transform(const float* Mx, const float* bias, float* y, int B, int C, int H, int W, int m,
-                                         void* stream) {
+extern "C" int sea_wino_output_transform(const float* Mx, const float* scale, const float* bias, int relu, float* y, int B,
+                                         int C, int H, int W, int m, void* stream) {
   int nTh, nTw;
   int64_t T;
   SEA_CHECK_ARG(Mx && y && wino_dims(B, C, H, W, m, 4, &nTh, &nTw, &T));
@@ -272,11 +294,11 @@ extern "C" int sea_wino_output_transform(const float* Mx, const float* bias, flo
   if (m == 2) {
     const int64_t total = T * (C / 4);
     hipLaunchKernelGGL((wino_output_kernel<2, 4>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, Mx,
-                       bias, y, C, H, W, nTh, nTw, T, total);
+                       scale, bias, relu, y, C, H, W, nTh, nTw, T, total);
   } else {
     const int64_t total = T * (C / 2);
     hipLaunchKernelGGL((wino_output_kernel<4, 2>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, Mx,
-                       bias, y, C, H, W, nTh, nTw, T, total);
+                       scale, bias, relu, y, C, H, W, nTh, nTw, T, total);
   }
   SEA_RETURN_LAST();
 }

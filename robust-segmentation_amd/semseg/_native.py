@@ -50,10 +50,12 @@ _SIGS = {
     "sea_nhwc_to_nchw": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _vp]),
     "sea_upsample_bilinear_fwd": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "sea_upsample_bilinear_bwd": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp]),
+    "sea_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _vp]),
+    "sea_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp]),
     "sea_wino_tiles": (_i64, [_i, _i, _i, _i]),
-    "sea_wino_input_transform": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sea_wino_input_transform": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sea_wino_filter_transform": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
-    "sea_wino_output_transform": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sea_wino_output_transform": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "sea_upsample_bilinear_nhwc_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i64, _vp]),
     "sea_upsample_bilinear_nhwc_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i64, _vp]),
 }
@@ -377,6 +379,30 @@ def upsample_bilinear_backward_cl(gy, in_size):
     return gx
 
 
+# ------------------------------------------------------------------------------------------------ M5
+def layernorm(x, weight, bias, eps: float):
+    """LayerNorm over the last dim of a contiguous fp32 tensor; returns (y, mean, rstd)."""
+    _dev(x, weight, bias)
+    x = _f32c(x)
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _check(lib().sea_layernorm_fwd(_p(x), _p(_f32c(weight)), _p(_f32c(bias)), _p(y), _p(mean), _p(rstd), rows, Cc,
+                                   float(eps), _stream()), "sea_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_backward(g, x, weight, mean, rstd):
+    _dev(g, x, weight, mean, rstd)
+    Cc = x.shape[-1]
+    dx = torch.empty_like(x)
+    _check(lib().sea_layernorm_bwd(_p(_f32c(g)), _p(_f32c(x)), _p(_f32c(weight)), _p(mean), _p(rstd), _p(dx),
+                                   x.numel() // Cc, Cc, _stream()), "sea_layernorm_bwd")
+    return dx
+
+
 # ------------------------------------------------------------------------------------------------ M4
 def wino_filter(weight, m: int, flip: bool):
     """(Cout,Cin,3,3) -> Winograd-domain filters: (A*A, Cin, Cout), or (A*A, Cout, Cin) rotated when flip."""
@@ -391,22 +417,30 @@ def wino_filter(weight, m: int, flip: bool):
     return U
 
 
-def wino_conv3x3_cl(x, U, m: int, bias=None):
-    """3x3 / stride 1 / pad 1 convolution of a dense channels_last (B,Cin,H,W) tensor with Winograd-domain
-    filters U (A*A, Cin, Cout); returns a channels_last (B,Cout,H,W) tensor."""
-    _dev(x, U, bias)
+def wino_conv3x3_cl(x, U, m: int, bias=None, scale=None, relu: bool = False, gate=None, gate_scale=None):
+    """3x3 / stride 1 / pad 1 convolution of a channels_last (B,Cin,H,W) tensor (or channel slice) with Winograd-domain
+    filters U (A*A, Cin, Cout); returns channels_last (B,Cout,H,W) = act(scale[c] * conv + bias[c]).
+    ``gate`` (same shape as x) / ``gate_scale``: the input is read as gate > 0 ? x * gate_scale[c] : 0."""
+    _dev(x, U, bias, scale, gate, gate_scale)
     B, Cin, H, W = x.shape
     A2, Ci, Cout = U.shape
-    if cl_pixel_stride(x) != Cin or Ci != Cin or A2 != (m + 2) ** 2 or Cout % 4:
-        raise SeaNativeError("wino_conv3x3_cl: dense channels_last float32 input and matching filters expected")
+    xps = cl_pixel_stride(x)  # a channel slice of a wider channels_last tensor is read in place
+    if xps is None or Ci != Cin or A2 != (m + 2) ** 2 or Cout % 4:
+        raise SeaNativeError("wino_conv3x3_cl: channels_last float32 input (or channel slice) and matching filters expected")
+    if gate is not None and (gate.shape != x.shape or cl_pixel_stride(gate) != Cin):
+        raise SeaNativeError("wino_conv3x3_cl: gate must match the input's shape and layout")
+    for v, n in ((bias, Cout), (scale, Cout), (gate_scale, Cin)):
+        if v is not None and (v.dtype != torch.float32 or v.numel() != n or not v.is_contiguous()):
+            raise SeaNativeError("wino_conv3x3_cl: per-channel vectors must be contiguous float32 of the channel count")
     L = lib()
     T = L.sea_wino_tiles(B, H, W, m)
     V = torch.empty(A2, T, Cin, dtype=torch.float32, device=x.device)
-    _check(L.sea_wino_input_transform(_p(x), _p(V), B, Cin, H, W, m, _stream()), "sea_wino_input_transform")
+    _check(L.sea_wino_input_transform(_p(x), xps, _p(gate), _p(gate_scale), _p(V), B, Cin, H, W, m, _stream()),
+           "sea_wino_input_transform")
     Mx = torch.bmm(V, U)  # (A*A) independent fp32 GEMMs: hipBLASLt strided-batched
     del V
     y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-    _check(L.sea_wino_output_transform(_p(Mx), _p(bias), _p(y), B, Cout, H, W, m, _stream()),
+    _check(L.sea_wino_output_transform(_p(Mx), _p(scale), _p(bias), int(relu), _p(y), B, Cout, H, W, m, _stream()),
            "sea_wino_output_transform")
     return y
 

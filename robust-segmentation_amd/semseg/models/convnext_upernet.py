@@ -31,6 +31,34 @@ CONVNEXT_SETTINGS = {
 }
 
 
+USE_HIP_LAYERNORM = True
+
+
+class _LayerNormHip(torch.autograd.Function):
+    """LayerNorm over the last dim through libsea_hip M5 (frozen affine parameters: input gradient only)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        from .. import _native as N
+        y, mean, rstd = N.layernorm(x, weight, bias, eps)
+        ctx.save_for_backward(x, weight, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import _native as N
+        x, weight, mean, rstd = ctx.saved_tensors
+        return N.layernorm_backward(g.contiguous(), x, weight, mean, rstd), None, None, None
+
+
+def _layer_norm(x, dim, weight, bias, eps):
+    if (USE_HIP_LAYERNORM and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and dim % 4 == 0
+            and dim <= 1024 and x.shape[-1] == dim and not weight.requires_grad and not bias.requires_grad
+            and not torch.is_autocast_enabled()):
+        return _LayerNormHip.apply(x, weight, bias, eps)
+    return F.layer_norm(x, (dim,), weight, bias, eps)
+
+
 class LayerNorm(nn.Module):
     """LayerNorm over the channel dim for NHWC ("channels_last") or NCHW ("channels_first") tensors."""
 
@@ -44,9 +72,9 @@ class LayerNorm(nn.Module):
 
     def forward(self, x):
         if self.data_format == "channels_last":
-            return F.layer_norm(x, (self.dim,), self.weight, self.bias, self.eps)
+            return _layer_norm(x, self.dim, self.weight, self.bias, self.eps)
         xt = _ToNHWC.apply(x) if _fast_layout_ok(x) else x.permute(0, 2, 3, 1)
-        y = F.layer_norm(xt, (self.dim,), self.weight, self.bias, self.eps)
+        y = _layer_norm(xt, self.dim, self.weight, self.bias, self.eps)
         y = y.permute(0, 3, 1, 2)
         return y.contiguous() if LN_CONTIGUOUS else y
 
@@ -286,25 +314,33 @@ class ConvNeXt(nn.Module):
         return tuple(feats)
 
 
-# Winograd tile for the head's large 3x3 convolutions: 2 = F(2x2,3x3) (fp32 error on par with a direct
-# convolution, 2.25x fewer multiplications), 4 = F(4x4,3x3) (4x fewer, ~20x larger rounding error), 0 = MIOpen.
-WINOGRAD_TILE = int(os.environ.get("SEA_WINOGRAD", "2"))
+# Winograd tile for the head's large 3x3 convolutions (env SEA_WINOGRAD): 4 = F(4x4,3x3), 4x fewer
+# multiplications than a direct convolution; 2 = F(2x2,3x3), 2.25x fewer; 0 = MIOpen's implicit-GEMM kernels.
+# All fp32.  Measured on MI355X (B=8, 512x512, ConvNeXt-T head, random init): APGD step 66.9 ms (0) / 44.4 ms
+# (2) / 34.3 ms (4); max |logit difference| against the MIOpen path 4.9e-7 (2) / 1.0e-6 (4) at logit scale
+# 0.25; unit-test error bounds vs float64: 2e-5 (2, same as direct fp32) / 3e-4 (4).  The config-#1 reference
+# parity test (tests/test_config1_parity.py) passes at the same tolerances for all three settings.
+WINOGRAD_TILE = int(os.environ.get("SEA_WINOGRAD", "4"))
 WINOGRAD_MIN_PIXELS = 32 * 32  # below this MIOpen's own kernels win (few tiles per GEMM)
 
 
 class _WinoConv3x3(torch.autograd.Function):
-    """conv2d(x, w, padding=1) for frozen 3x3 filters: libsea_hip Winograd transforms around a hipBLASLt
-    batched GEMM, forward and input gradient (the filters get no gradient: attack-time weights are frozen)."""
+    """act(scale[c] * conv2d(x, w, padding=1) + shift[c]) for frozen 3x3 filters: libsea_hip Winograd transforms
+    around a hipBLASLt batched GEMM, forward and input gradient (the filters get no gradient: attack-time
+    weights are frozen).  With ``relu`` the eval-mode BatchNorm (scale, shift) and the ReLU of a ConvModule run
+    in the output transform, and their backward in the input transform of the gradient convolution."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, m, cache):
+    def forward(ctx, x, weight, m, cache, scale, shift, relu):
         from .. import _native as N
         key = (weight.data_ptr(), weight._version, m)
         if cache.get("key") != key:
-            cache.clear()
             cache.update(key=key, fwd=N.wino_filter(weight.contiguous(), m, False), bwd=None)
-        ctx.cache, ctx.m, ctx.weight = cache, m, weight
-        return N.wino_conv3x3_cl(_dense_cl(x), cache["fwd"], m, bias)
+        ctx.cache, ctx.m, ctx.weight, ctx.relu = cache, m, weight, relu
+        y = N.wino_conv3x3_cl(_dense_cl(x), cache["fwd"], m, bias=shift, scale=scale, relu=relu)
+        if relu:
+            ctx.save_for_backward(y, scale)
+        return y
 
     @staticmethod
     def backward(ctx, gy):
@@ -312,7 +348,28 @@ class _WinoConv3x3(torch.autograd.Function):
         cache = ctx.cache
         if cache.get("bwd") is None:
             cache["bwd"] = N.wino_filter(ctx.weight.contiguous(), ctx.m, True)
-        return N.wino_conv3x3_cl(_dense_cl(gy), cache["bwd"], ctx.m), None, None, None, None
+        gate, gscale = ctx.saved_tensors if ctx.relu else (None, None)
+        g = gy if N.cl_pixel_stride(gy) is not None else gy.contiguous(memory_format=_CL)  # slices read in place
+        gx = N.wino_conv3x3_cl(g, cache["bwd"], ctx.m, gate=gate, gate_scale=gscale)
+        return gx, None, None, None, None, None, None
+
+
+def _folded_bn(bn, conv_bias, cache):
+    """eval-mode BatchNorm as y = scale[c] * x + shift[c] (cached until a buffer / parameter changes)"""
+    ts = (bn.weight, bn.bias, bn.running_mean, bn.running_var, conv_bias)
+    key = tuple((t.data_ptr(), t._version) for t in ts if t is not None)
+    if cache.get("bn_key") != key:
+        with torch.no_grad():
+            scale = torch.rsqrt(bn.running_var + bn.eps)
+            if bn.weight is not None:
+                scale = scale * bn.weight
+            shift = -bn.running_mean * scale
+            if bn.bias is not None:
+                shift = shift + bn.bias
+            if conv_bias is not None:
+                shift = shift + scale * conv_bias
+        cache.update(bn_key=key, scale=scale.float().contiguous(), shift=shift.float().contiguous())
+    return cache["scale"], cache["shift"]
 
 
 def _wino_ok(conv, x):
@@ -324,6 +381,18 @@ def _wino_ok(conv, x):
             and not torch.is_autocast_enabled())
 
 
+USE_GEMM_POINTWISE = True
+
+
+def _pointwise_ok(mod, x):
+    conv, bn = mod.conv, mod.batch_norm
+    return (USE_GEMM_POINTWISE and x.is_cuda and x.dtype == torch.float32 and conv.kernel_size == (1, 1)
+            and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1 and not bn.training
+            and bn.track_running_stats and isinstance(mod.activation, nn.ReLU)
+            and not any(p.requires_grad for p in mod.parameters()) and not torch.is_autocast_enabled()
+            and x.is_contiguous(memory_format=torch.channels_last))
+
+
 class ConvModule(nn.Module):
     """bias-free conv + BatchNorm + ReLU (uperforseg.py:119-146)."""
 
@@ -333,11 +402,32 @@ class ConvModule(nn.Module):
         self.batch_norm = nn.BatchNorm2d(cout)
         self.activation = nn.ReLU()
 
+    def _pointwise(self, x):
+        """1x1 ConvModule on a channels_last tensor with frozen weights and eval-mode BatchNorm: one hipBLASLt GEMM
+        (the BatchNorm folded into its weights and bias) + ReLU; no MIOpen layout transposes, no BatchNorm kernels."""
+        if not hasattr(self, "_wino_cache"):
+            object.__setattr__(self, "_wino_cache", {})
+        cache, w = self._wino_cache, self.conv.weight
+        scale, shift = _folded_bn(self.batch_norm, self.conv.bias, cache)
+        key = (w.data_ptr(), w._version, cache["bn_key"])
+        if cache.get("pw_key") != key:
+            with torch.no_grad():
+                cache.update(pw_key=key, pw_w=(w.view(w.shape[0], -1) * scale[:, None]).contiguous())
+        y = F.linear(x.permute(0, 2, 3, 1), cache["pw_w"], shift)  # (B,H,W,Cout)
+        return F.relu(y, inplace=True).permute(0, 3, 1, 2)
+
     def forward(self, x):
+        if _pointwise_ok(self, x):
+            return self._pointwise(x)
         if _wino_ok(self.conv, x):
             if not hasattr(self, "_wino_cache"):
                 object.__setattr__(self, "_wino_cache", {})
-            y = _WinoConv3x3.apply(x, self.conv.weight, self.conv.bias, WINOGRAD_TILE, self._wino_cache)
+            bn = self.batch_norm
+            if (not bn.training and bn.track_running_stats and isinstance(self.activation, nn.ReLU)
+                    and not any(p.requires_grad for p in bn.parameters())):
+                scale, shift = _folded_bn(bn, self.conv.bias, self._wino_cache)
+                return _WinoConv3x3.apply(x, self.conv.weight, WINOGRAD_TILE, self._wino_cache, scale, shift, True)
+            y = _WinoConv3x3.apply(x, self.conv.weight, WINOGRAD_TILE, self._wino_cache, None, self.conv.bias, False)
         else:
             y = self.conv(x)
         return self.activation(self.batch_norm(y))

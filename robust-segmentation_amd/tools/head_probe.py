@@ -66,11 +66,11 @@ def main():
     for h in hooks:
         h.remove()
 
-    for nhwc, tile in ((True, 0), (True, 2), (True, 4), (False, 0), (True, 2), (True, 0)):
+    for nhwc, tile in ((True, 4), (True, 2), (True, 4)):
         M.USE_HIP_UPSAMPLE_NHWC, M.WINOGRAD_TILE = nhwc, tile  # nhwc=False also disables the fused cat/add
         print(f"NHWC head={nhwc} winograd tile={tile}: {timed(lambda: step(model, x)):.2f} ms / forward+backward",
               flush=True)
-    M.USE_HIP_UPSAMPLE_NHWC, M.WINOGRAD_TILE = True, 2
+    M.USE_HIP_UPSAMPLE_NHWC, M.WINOGRAD_TILE = True, 4
     with torch.no_grad():
         M.WINOGRAD_TILE = 0
         ref = model(x)
@@ -78,13 +78,25 @@ def main():
             M.WINOGRAD_TILE = tile
             d = (model(x) - ref).abs().max().item()
             print(f"winograd tile={tile}: max |logit diff| vs MIOpen = {d:.3e} (logit scale {ref.abs().max().item():.3f})")
-    M.WINOGRAD_TILE = 2
+    M.WINOGRAD_TILE = 4
 
     from torch.profiler import ProfilerActivity, profile
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
         for _ in range(3):
             step(model, x)
         torch.cuda.synchronize()
+    seen = {}
+    for e in prof.events():  # who issues the big layout / slice copies?
+        if e.name in ("aten::copy_", "aten::contiguous", "aten::clone") and e.input_shapes and e.input_shapes[0] \
+                and len(e.input_shapes[0]) == 4 and e.input_shapes[0][1] >= 256 and e.input_shapes[0][2] >= 64:
+            chain, q = [], e.cpu_parent
+            while q is not None and len(chain) < 5:
+                chain.append(q.name)
+                q = q.cpu_parent
+            k = (e.name, str(e.input_shapes[0]), " <- ".join(chain))
+            seen[k] = seen.get(k, 0) + 1
+    for k, v in seen.items():
+        print(f"{v:3d}x {k[0]} {k[1]} <- {k[2]}")
     print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=45,
                                                               max_name_column_width=48, max_shapes_column_width=70))
 

@@ -198,6 +198,52 @@ def main():
         for k, ms in t.items():
             report(k, ms, 8 * xn.numel())
 
+    # ---------------- M5 LayerNorm / M4 Winograd transforms --------------------------------------------
+    for rows, Cc in ((8 * 256 * 256, 48), (8 * 128 * 128, 96), (8 * 64 * 64, 192), (8 * 32 * 32, 384), (8 * 16 * 16, 768)):
+        xl = torch.randn(rows, Cc, device="cuda")
+        wl, bl = torch.randn(Cc, device="cuda"), torch.randn(Cc, device="cuda")
+        _, mean, rstd = N.layernorm(xl, wl, bl, 1e-6)
+        t = timeit({
+            f"M5 layernorm fwd rows={rows} C={Cc}": lambda: N.layernorm(xl, wl, bl, 1e-6),
+            f"ATen layer_norm fwd rows={rows} C={Cc}": lambda: F.layer_norm(xl, (Cc,), wl, bl, 1e-6),
+        }, rounds=7)
+        for k, ms in t.items():
+            report(k, ms, 8 * xl.numel())
+        gl = torch.randn(rows, Cc, device="cuda")
+        t = timeit({f"M5 layernorm bwd rows={rows} C={Cc}": lambda: N.layernorm_backward(gl, xl, wl, mean, rstd)}, rounds=7)
+        for k, ms in t.items():
+            report(k, ms, 12 * xl.numel())
+    for m in (2, 4):
+        for Cin, Cout in ((2048, 512), (512, 512)):
+            xw = torch.randn(B, Cin, 128, 128, device="cuda").contiguous(memory_format=torch.channels_last)
+            ww = torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.01
+            U = N.wino_filter(ww, m, False)
+            T = N.lib().sea_wino_tiles(B, 128, 128, m)
+            A2 = (m + 2) ** 2
+            V = torch.empty(A2, T, Cin, device="cuda")
+            Mx = torch.empty(A2, T, Cout, device="cuda")
+            yw = torch.empty(B, Cout, 128, 128, device="cuda").contiguous(memory_format=torch.channels_last)
+            L = N.lib()
+            st = torch.cuda.current_stream().cuda_stream
+            t = timeit({
+                f"M4 winograd F({m}x{m}) input transform {Cin}ch 128x128": lambda: L.sea_wino_input_transform(
+                    xw.data_ptr(), Cin, None, None, V.data_ptr(), B, Cin, 128, 128, m, st),
+                f"M4 winograd F({m}x{m}) output transform {Cout}ch 128x128": lambda: L.sea_wino_output_transform(
+                    Mx.data_ptr(), None, None, 0, yw.data_ptr(), B, Cout, 128, 128, m, st),
+            }, rounds=7)
+            report(f"M4 winograd F({m}x{m}) input transform {Cin}ch 128x128", t[f"M4 winograd F({m}x{m}) input transform {Cin}ch 128x128"],
+                   4 * (xw.numel() + V.numel()))
+            report(f"M4 winograd F({m}x{m}) output transform {Cout}ch 128x128", t[f"M4 winograd F({m}x{m}) output transform {Cout}ch 128x128"],
+                   4 * (yw.numel() + Mx.numel()))
+            t = timeit({
+                f"M4 winograd F({m}x{m}) conv3x3 {Cin}->{Cout} 128x128 (transforms + hipBLASLt bmm)": lambda: N.wino_conv3x3_cl(xw, U, m),
+                f"MIOpen conv3x3 {Cin}->{Cout} 128x128": lambda: F.conv2d(xw, ww, padding=1),
+            }, rounds=5)
+            flops = 2.0 * B * 128 * 128 * Cin * Cout * 9
+            for k, ms in t.items():
+                print(f"{k:84s} {ms:9.4f} ms   {flops / ms / 1e9:8.1f} direct-equivalent TFLOP/s", flush=True)
+            del xw, ww, U, V, Mx, yw
+
     # ---------------- K3 ----------------------------------------------------------------------------
     for C in (21, 151):
         pred = torch.randint(0, C, (B, H, W), device="cuda", dtype=torch.uint8)

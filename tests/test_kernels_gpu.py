@@ -506,6 +506,79 @@ def test_upernet_head_with_and_without_hip_upsample(N):
         assert ((outs[k][1] - outs[2][1]).abs() > 1e-3 * gmax).float().mean() < 0.01
 
 
+# ------------------------------------------------------------------------------------------------ M5
+@pytest.mark.parametrize("shape", [(2, 16, 16, 48), (3, 7, 5, 96), (1, 9, 192), (5, 384), (2, 3, 768), (7, 4),
+                                   (3, 1024), (11, 100), (1, 200, 300, 96)])
+def test_layernorm_forward_and_input_gradient(N, shape):
+    import torch.nn.functional as F
+    C = shape[-1]
+    g = torch.Generator().manual_seed(C + len(shape))
+    x = torch.randn(shape, generator=g) * 2 + 0.5
+    w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    gy = torch.randn(shape, generator=g)
+    xd = x.double().requires_grad_(True)
+    ref = F.layer_norm(xd, (C,), w.double(), b.double(), 1e-6)
+    (gx_ref,) = torch.autograd.grad(ref, xd, gy.double())
+    y, mean, rstd = N.layernorm(dev(x), dev(w), dev(b), 1e-6)
+    torch.testing.assert_close(y.cpu().double(), ref.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(mean.cpu().double(), x.double().reshape(-1, C).mean(1), rtol=1e-5, atol=1e-6)
+    dx = N.layernorm_backward(dev(gy), dev(x), dev(w), mean, rstd)
+    torch.testing.assert_close(dx.cpu().double(), gx_ref, rtol=1e-4, atol=1e-5 * max(1.0, gx_ref.abs().max().item()))
+    assert torch.equal(y, N.layernorm(dev(x), dev(w), dev(b), 1e-6)[0])
+    with pytest.raises(N.SeaNativeError):
+        N.layernorm(x, w, b, 1e-6)  # CPU tensors refused
+
+
+def test_convnext_layernorm_module_uses_hip_and_matches_aten(N):
+    from semseg.models import convnext_upernet as M
+    ln = M.LayerNorm(96).cuda()
+    with torch.no_grad():
+        ln.weight.normal_()
+        ln.bias.normal_()
+    x = torch.randn(2, 20, 24, 96, device="cuda")
+    outs = []
+    for frozen in (True, False):  # parameters that require grad stay on ATen
+        for p in ln.parameters():
+            p.requires_grad_(not frozen)
+        xi = x.clone().requires_grad_(True)
+        y = ln(xi)
+        assert (type(y.grad_fn).__name__ == "_LayerNormHipBackward") == frozen
+        (gx,) = torch.autograd.grad((y * y).sum(), xi)
+        outs.append((y.detach(), gx))
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-4, atol=1e-4)
+
+
+def test_convmodule_pointwise_gemm_matches_miopen(N):
+    from semseg.models import convnext_upernet as M
+    torch.manual_seed(2)
+    mod = M.ConvModule(96, 64, 1).cuda().eval()
+    mod.batch_norm.running_mean.normal_()
+    mod.batch_norm.running_var.uniform_(0.5, 2.0)
+    with torch.no_grad():
+        mod.batch_norm.weight.uniform_(0.5, 1.5)
+        mod.batch_norm.bias.normal_()
+    for p in mod.parameters():
+        p.requires_grad_(False)
+    x = torch.randn(2, 96, 20, 28, device="cuda").contiguous(memory_format=torch.channels_last)
+    outs = []
+    try:
+        for flag in (True, False):
+            M.USE_GEMM_POINTWISE = flag
+            assert M._pointwise_ok(mod, x) == flag
+            xi = x.clone().requires_grad_(True)
+            y = mod(xi)
+            (gx,) = torch.autograd.grad((y * y).sum(), xi)
+            outs.append((y.detach(), gx))
+    finally:
+        M.USE_GEMM_POINTWISE = True
+    assert outs[0][0].shape == outs[1][0].shape and outs[0][0].is_contiguous(memory_format=torch.channels_last)
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-4, atol=1e-4)
+    mod.train()
+    assert not M._pointwise_ok(mod, x)  # training-mode BatchNorm keeps the reference composition
+
+
 # ------------------------------------------------------------------------------------------------ M4
 @pytest.mark.parametrize("m", [2, 4])
 @pytest.mark.parametrize("case", [(2, 8, 12, 16, 16), (1, 64, 32, 33, 31), (2, 4, 4, 5, 7), (1, 16, 8, 1, 1),
@@ -532,6 +605,21 @@ def test_winograd_conv3x3_forward_and_input_gradient(N, m, case):
     Ub = N.wino_filter(dev(w), m, True)
     gx = N.wino_conv3x3_cl(dev(gy).contiguous(memory_format=cl), Ub, m)
     torch.testing.assert_close(gx.cpu().double(), gx_ref, rtol=tol, atol=tol)
+    # fused epilogue act(scale * conv + shift) and its backward as a gated / scaled prologue of the gradient conv
+    scale = torch.rand(Cout, generator=g) + 0.5
+    ref_nb = F.conv2d(xd, w.double(), None, padding=1)
+    y2 = N.wino_conv3x3_cl(dev(x).contiguous(memory_format=cl), U, m, bias=dev(bias), scale=dev(scale), relu=True)
+    ref2 = torch.relu(ref_nb * scale.double()[None, :, None, None] + bias.double()[None, :, None, None])
+    torch.testing.assert_close(y2.cpu().double(), ref2.detach(), rtol=2 * tol, atol=2 * tol)
+    gate = torch.randn(B, Cout, H, W, generator=g)
+    (gx_ref2,) = torch.autograd.grad(ref_nb, xd, gy.double() * scale.double()[None, :, None, None] * (gate > 0))
+    gx2 = N.wino_conv3x3_cl(dev(gy).contiguous(memory_format=cl), Ub, m, gate=dev(gate).contiguous(memory_format=cl),
+                            gate_scale=dev(scale))
+    torch.testing.assert_close(gx2.cpu().double(), gx_ref2, rtol=2 * tol, atol=2 * tol)
+    # the gradient convolution reads a channel slice of a wider NHWC tensor in place
+    wide = torch.zeros(B, Cout + 8, H, W, device="cuda").contiguous(memory_format=cl)
+    wide[:, 4:4 + Cout] = dev(gy)
+    torch.testing.assert_close(N.wino_conv3x3_cl(wide[:, 4:4 + Cout], Ub, m), gx, rtol=0, atol=0)
     # deterministic
     assert torch.equal(y, N.wino_conv3x3_cl(dev(x).contiguous(memory_format=cl), U, m, dev(bias)))
     with pytest.raises(N.SeaNativeError):
@@ -547,7 +635,7 @@ def test_convmodule_winograd_matches_miopen(N):
     for p in mod.parameters():
         p.requires_grad_(False)
     x = torch.randn(2, 64, 40, 36, device="cuda").contiguous(memory_format=torch.channels_last)
-    outs = []
+    outs, default_tile = [], M.WINOGRAD_TILE
     try:
         for tile in (2, 4, 0):
             M.WINOGRAD_TILE = tile
@@ -556,7 +644,7 @@ def test_convmodule_winograd_matches_miopen(N):
             (gx,) = torch.autograd.grad((y * y).sum(), xi)
             outs.append((y.detach(), gx))
     finally:
-        M.WINOGRAD_TILE = 2
+        M.WINOGRAD_TILE = default_tile
     for k, tol in ((0, 2e-5), (1, 3e-4)):
         torch.testing.assert_close(outs[k][0], outs[2][0], rtol=tol, atol=tol)
         torch.testing.assert_close(outs[k][1], outs[2][1], rtol=tol * 10, atol=tol * 10)
@@ -567,6 +655,7 @@ def test_convmodule_winograd_matches_miopen(N):
     # in-place weight updates invalidate the cached Winograd-domain filters
     for p in mod.parameters():
         p.requires_grad_(False)
+    M.WINOGRAD_TILE = 2
     y0 = mod(x)
     mod.conv.weight.mul_(2.0)
     y1 = mod(x)
@@ -574,7 +663,7 @@ def test_convmodule_winograd_matches_miopen(N):
     try:
         torch.testing.assert_close(y1, mod(x), rtol=2e-5, atol=2e-5)
     finally:
-        M.WINOGRAD_TILE = 2
+        M.WINOGRAD_TILE = default_tile
     assert not torch.equal(y0, y1)
 
 

@@ -247,16 +247,16 @@ int sea_upsample_bilinear_nhwc_bwd(const float* gy, float* gx, int B, int C, int
  *   sea_wino_filter_transform:  w (Cout,Cin,3,3) -> U (A*A, Cin, Cout)             (flip = 0, forward)
  *                               w -> U (A*A, Cout, Cin) of the 180-degree rotated filters (flip = 1: the
  *                               convolution that yields the input gradient from the output gradient)
- *   sea_wino_output_transform:  M (A*A, T, C) -> y (B,H,W,C) = act(scale[c] * conv + bias[c]); scale / bias
- *                               may be NULL, act = ReLU when relu != 0.  With scale/bias = the folded
+ *   sea_wino_output_transform:  M (A*A, T, C) -> y (B,H,W,C) = act(scale[c] * (conv + addend) + bias[c]);
+ *                               addend (B,H,W,C) / scale / bias may be NULL, act = ReLU when relu != 0.  With scale/bias = the folded
  *                               eval-mode BatchNorm this is the whole ConvModule (uperforseg.py:119-146).
  * C % 4 == 0, 16-byte aligned pointers. */
 int64_t sea_wino_tiles(int B, int H, int W, int m);
 int sea_wino_input_transform(const float* x, int64_t x_pixel_stride, const float* gate, const float* scale,
                              float* V, int B, int C, int H, int W, int m, void* stream);
 int sea_wino_filter_transform(const float* w, float* U, int Cout, int Cin, int m, int flip, void* stream);
-int sea_wino_output_transform(const float* M, const float* scale, const float* bias, int relu, float* y,
-                              int B, int C, int H, int W, int m, void* stream);
+int sea_wino_output_transform(const float* M, const float* addend, const float* scale, const float* bias,
+                              int relu, float* y, int B, int C, int H, int W, int m, void* stream);
 
 /* M5  (model side) LayerNorm over the last dimension of a (rows, C) fp32 tensor with few channels (ConvNeXt:
  * C = 48..768, eps 1e-6; convnext_orig.py:19-40), forward and input gradient (w, b frozen).  A row is owned
@@ -265,6 +265,20 @@ int sea_layernorm_fwd(const float* x, const float* w, const float* b, float* y, 
                       int64_t rows, int C, float eps, void* stream);
 int sea_layernorm_bwd(const float* g, const float* x, const float* w, const float* mean, const float* rstd,
                       float* dx, int64_t rows, int C, void* stream);
+
+/* M6  (model side) the FPN bottleneck without up-sampling its coarse inputs (uperforseg.py:255-262).  Channel
+ * mixing commutes with bilinear up-sampling, so for an input that is an xs up-sampling (s >= 3) the nine 3x3
+ * taps are applied as one GEMM at the coarse resolution, G = f @ W -> (B,h,w,9,C), and only a gather is left
+ * at the output resolution:
+ *   sea_tap_gather_fwd: extra (B,H,W,C) (+)= sum_taps shift_tap(up(G[..., tap, :]))   (accumulate != 0: +=)
+ *   sea_tap_gather_bwd: gz (B,H,W,C) -> dG (B,h,w,9,C), the exact adjoint (then df = dG @ W^T)
+ *   sea_gate_scale    : out = gate > 0 ? g * scale[c] : 0, the backward of relu(scale * z + shift) (NHWC)
+ * `extra` enters sea_wino_output_transform as `addend`.  C % 4 == 0, 16-byte aligned. */
+int sea_tap_gather_fwd(const float* G, float* extra, int accumulate, int B, int C, int h, int w, int H, int W,
+                       void* stream);
+int sea_tap_gather_bwd(const float* gz, float* dG, int B, int C, int h, int w, int H, int W, void* stream);
+int sea_gate_scale(const float* g, const float* gate, const float* scale, float* out, int64_t pixels, int C,
+                   void* stream);
 
 /* M3  (model side) NCHW <-> NHWC layout changes of the ConvNeXt block through LDS-tiled transposes,
  * fused with the per-channel layer scale and the residual add (convnext_orig.py:75-86: the two

@@ -35,6 +35,7 @@ SOURCES = [
     ("transpose_kernels.hip", ["-ffp-contract=off"]),
     ("wino_kernels.hip", []),
     ("ln_kernels.hip", []),
+    ("fpn_fused.hip", []),
     ("greedy_host.cpp", ["-ffp-contract=off"]),
     ("api_misc.cpp", []),
 ]

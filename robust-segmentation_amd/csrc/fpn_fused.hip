@@ -1,0 +1,170 @@
+// M6 (model side): the FPN bottleneck of the UperNet head without up-sampling its coarse inputs
+// (semseg/models/uperforseg.py:255-262:  fpn_bottleneck(cat([f0, up(f1), up(f2), up(f3)]))).
+//
+// A 3x3 convolution is  sum_taps Shift_tap o W_tap  with W_tap a pure channel mixing, and channel mixing commutes
+// with bilinear up-sampling:  W_tap up(f) = up(W_tap f).  For an input that is an x4 / x8 up-sampling the nine
+// channel mixings therefore run at the COARSE resolution (one GEMM, 16x / 64x fewer rows than at the output
+// resolution, 4x / 16x fewer multiplications than even Winograd F(4x4,3x3)), and what is left at the output
+// resolution is HBM-bound:
+//   forward :  extra[b,Y,X,:] (+)= sum_{a,b in 3x3, (Y+a-1, X+b-1) inside} bilinear(G[..., tap(a,b), :])(Y+a-1, X+b-1)
+//              G = f @ W  laid out (B,h,w,9,C); `extra` enters the Winograd output transform as an addend
+//   backward:  dG[b,y,x,tap,:] = sum over the bilinear footprint (P,Q) of (y,x) of wy(P,y) wx(Q,x) gz[b,P-a+1,Q-b+1,:]
+//              then df = dG @ W^T at the coarse resolution
+// Lanes run along channels (float4): every access is coalesced; the 9 taps share one pass over the footprint window.
+#include "sea_common.h"
+#include "bilinear_map.h"
+
+namespace sea {
+
+__global__ __launch_bounds__(256) void tap_gather_fwd_kernel(const float4* __restrict__ G, float4* __restrict__ extra,
+                                                             int accumulate, int CG, int h, int w, int H, int W, float rh,
+                                                             float rw, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % CG);
+    int64_t p = i / CG;
+    const int X = (int)(p % W);
+    p /= W;
+    const int Y = (int)(p % H);
+    const int b = (int)(p / H);
+    AxisMapU my[3], mx[3];
+    bool vy[3], vx[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int P = Y + a - 1, Q = X + a - 1;
+      vy[a] = P >= 0 && P < H;
+      vx[a] = Q >= 0 && Q < W;
+      my[a] = axis_map_u(vy[a] ? P : Y, rh, h);
+      mx[a] = axis_map_u(vx[a] ? Q : X, rw, w);
+    }
+    float4 acc = accumulate ? extra[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* Gb = G + (int64_t)b * h * w * 9 * CG + cg;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (!vy[a]) continue;
+      const float ly = my[a].lam, uy = 1.f - ly;
+#pragma unroll
+      for (int bq = 0; bq < 3; ++bq) {
+        if (!vx[bq]) continue;
+        const int tap = a * 3 + bq;
+        const float lx = mx[bq].lam, ux = 1.f - lx;
+        const float4 v00 = Gb[(((int64_t)my[a].i0 * w + mx[bq].i0) * 9 + tap) * CG];
+        const float4 v01 = Gb[(((int64_t)my[a].i0 * w + mx[bq].i1) * 9 + tap) * CG];
+        const float4 v10 = Gb[(((int64_t)my[a].i1 * w + mx[bq].i0) * 9 + tap) * CG];
+        const float4 v11 = Gb[(((int64_t)my[a].i1 * w + mx[bq].i1) * 9 + tap) * CG];
+        acc.x += uy * (ux * v00.x + lx * v01.x) + ly * (ux * v10.x + lx * v11.x);
+        acc.y += uy * (ux * v00.y + lx * v01.y) + ly * (ux * v10.y + lx * v11.y);
+        acc.z += uy * (ux * v00.z + lx * v01.z) + ly * (ux * v10.z + lx * v11.z);
+        acc.w += uy * (ux * v00.w + lx * v01.w) + ly * (ux * v10.w + lx * v11.w);
+      }
+    }
+    extra[i] = acc;
+  }
+}
+
+// one lane = (coarse pixel, 4 channels): a single pass over the (footprint + 1 ring) window of gz feeds all 9 taps
+__global__ __launch_bounds__(256) void tap_gather_bwd_kernel(const float4* __restrict__ gz, float4* __restrict__ dG, int CG,
+                                                             int h, int w, int H, int W, float rh, float rw,
+                                                             int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % CG);
+    int64_t p = i / CG;
+    const int xq = (int)(p % w);
+    p /= w;
+    const int yq = (int)(p % h);
+    const int b = (int)(p / h);
+    const int Plo = first_dst_ge(yq - 1, rh, h, H), Phi = first_dst_ge(yq + 1, rh, h, H);
+    const int Qlo = first_dst_ge(xq - 1, rw, w, W), Qhi = first_dst_ge(xq + 1, rw, w, W);
+    const int R0 = max(Plo - 1, 0), R1 = min(Phi + 1, H), S0 = max(Qlo - 1, 0), S1 = min(Qhi + 1, W);
+    const float4* gb = gz + (int64_t)b * H * W * CG + cg;
+    float4 acc[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int bq = 0; bq < 3; ++bq) acc[a][bq] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int R = R0; R < R1; ++R) {
+      float wya[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const int P = R + a - 1;  // the tap-a source row that reads gz row R
+        wya[a] = (P >= Plo && P < Phi) ? axis_coef(P, yq, rh, h) : 0.f;
+      }
+      if (wya[0] == 0.f && wya[1] == 0.f && wya[2] == 0.f) continue;
+      float4 rb[3];
+#pragma unroll
+      for (int bq = 0; bq < 3; ++bq) rb[bq] = make_float4(0.f, 0.f, 0.f, 0.f);
+      // sliding column coefficients: c[bq] = weight of Q = S + bq - 1
+      float c0 = (S0 - 1 >= Qlo && S0 - 1 < Qhi) ? axis_coef(S0 - 1, xq, rw, w) : 0.f;
+      float c1 = (S0 >= Qlo && S0 < Qhi) ? axis_coef(S0, xq, rw, w) : 0.f;
+      for (int S = S0; S < S1; ++S) {
+        const float c2 = (S + 1 >= Qlo && S + 1 < Qhi) ? axis_coef(S + 1, xq, rw, w) : 0.f;
+        const float4 g = gb[((int64_t)R * W + S) * CG];
+        rb[0].x = fmaf(c0, g.x, rb[0].x); rb[0].y = fmaf(c0, g.y, rb[0].y); rb[0].z = fmaf(c0, g.z, rb[0].z); rb[0].w = fmaf(c0, g.w, rb[0].w);
+        rb[1].x = fmaf(c1, g.x, rb[1].x); rb[1].y = fmaf(c1, g.y, rb[1].y); rb[1].z = fmaf(c1, g.z, rb[1].z); rb[1].w = fmaf(c1, g.w, rb[1].w);
+        rb[2].x = fmaf(c2, g.x, rb[2].x); rb[2].y = fmaf(c2, g.y, rb[2].y); rb[2].z = fmaf(c2, g.z, rb[2].z); rb[2].w = fmaf(c2, g.w, rb[2].w);
+        c0 = c1;
+        c1 = c2;
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int bq = 0; bq < 3; ++bq) {
+          acc[a][bq].x = fmaf(wya[a], rb[bq].x, acc[a][bq].x);
+          acc[a][bq].y = fmaf(wya[a], rb[bq].y, acc[a][bq].y);
+          acc[a][bq].z = fmaf(wya[a], rb[bq].z, acc[a][bq].z);
+          acc[a][bq].w = fmaf(wya[a], rb[bq].w, acc[a][bq].w);
+        }
+    }
+    float4* out = dG + (((int64_t)b * h + yq) * w + xq) * 9 * CG + cg;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int bq = 0; bq < 3; ++bq) out[(a * 3 + bq) * CG] = acc[a][bq];
+  }
+}
+
+// out = gate > 0 ? g * scale[c] : 0   (backward of y = relu(scale * z + shift) w.r.t. z, NHWC dense)
+__global__ __launch_bounds__(256) void gate_scale_kernel(const float4* __restrict__ g, const float4* __restrict__ gate,
+                                                         const float4* __restrict__ scale, float4* __restrict__ out, int CG,
+                                                         int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 s = scale[i % CG], gv = g[i], t = gate[i];
+    out[i] = make_float4(t.x > 0.f ? gv.x * s.x : 0.f, t.y > 0.f ? gv.y * s.y : 0.f, t.z > 0.f ? gv.z * s.z : 0.f,
+                         t.w > 0.f ? gv.w * s.w : 0.f);
+  }
+}
+
+}  // namespace sea
+
+using namespace sea;
+
+// G (B,h,w,9,C) coarse per-tap maps -> extra (B,H,W,C) (+)= sum over the 3x3 taps of the shifted up-samplings
+extern "C" int sea_tap_gather_fwd(const float* G, float* extra, int accumulate, int B, int C, int h, int w, int H, int W,
+                                  void* stream) {
+  SEA_CHECK_ARG(G && extra && B > 0 && C > 0 && (C % 4) == 0 && h > 0 && w > 0 && H >= h && W >= w);
+  SEA_CHECK_ARG(((((uintptr_t)G) | ((uintptr_t)extra)) & 15) == 0);
+  const int64_t total = (int64_t)B * H * W * (C / 4);
+  hipLaunchKernelGGL(tap_gather_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)G, (float4*)extra, accumulate, C / 4, h, w, H, W, (float)h / (float)H,
+                     (float)w / (float)W, total);
+  SEA_RETURN_LAST();
+}
+
+// gz (B,H,W,C) gradient at the convolution output -> dG (B,h,w,9,C)
+extern "C" int sea_tap_gather_bwd(const float* gz, float* dG, int B, int C, int h, int w, int H, int W, void* stream) {
+  SEA_CHECK_ARG(gz && dG && B > 0 && C > 0 && (C % 4) == 0 && h > 0 && w > 0 && H >= h && W >= w);
+  SEA_CHECK_ARG(((((uintptr_t)gz) | ((uintptr_t)dG)) & 15) == 0);
+  const int64_t total = (int64_t)B * h * w * (C / 4);
+  hipLaunchKernelGGL(tap_gather_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)gz, (float4*)dG, C / 4, h, w, H, W, (float)h / (float)H, (float)w / (float)W, total);
+  SEA_RETURN_LAST();
+}
+
+extern "C" int sea_gate_scale(const float* g, const float* gate, const float* scale, float* out, int64_t pixels, int C,
+                              void* stream) {
+  SEA_CHECK_ARG(g && gate && scale && out && pixels > 0 && C > 0 && (C % 4) == 0);
+  SEA_CHECK_ARG(((((uintptr_t)g) | ((uintptr_t)gate) | ((uintptr_t)scale) | ((uintptr_t)out)) & 15) == 0);
+  const int64_t total = pixels * (C / 4);
+  hipLaunchKernelGGL(gate_scale_kernel, dim3(grid_for(total, 256 * 2)), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)g, (const float4*)gate, (const float4*)scale, (float4*)out, C / 4, total);
+  SEA_RETURN_LAST();
+}

@@ -13,34 +13,9 @@
 // loss_upsampled.hip).
 // Source-index rule = ATen: src = r*(dst+0.5)-0.5 clamped at 0, i0=floor(src), i1=min(i0+1,n-1).
 #include "sea_common.h"
+#include "bilinear_map.h"
 
 namespace sea {
-
-struct AxisMapU {
-  int i0, i1;
-  float lam;
-};
-
-__device__ __forceinline__ AxisMapU axis_map_u(int dst, float r, int n_in) {
-  float src = r * ((float)dst + 0.5f) - 0.5f;
-  src = src < 0.f ? 0.f : src;
-  AxisMapU m;
-  m.i0 = (int)src;
-  if (m.i0 > n_in - 1) m.i0 = n_in - 1;
-  m.i1 = m.i0 + ((m.i0 < n_in - 1) ? 1 : 0);
-  m.lam = src - (float)m.i0;
-  return m;
-}
-
-__device__ __forceinline__ int first_dst_ge(int t, float r, int n_in, int n_out) {
-  if (t <= 0) return 0;
-  if (t > n_in - 1) return n_out;
-  int d = (int)ceilf(((float)t + 0.5f) / r - 0.5f);
-  d = d < 0 ? 0 : (d > n_out ? n_out : d);
-  while (d > 0 && axis_map_u(d - 1, r, n_in).i0 >= t) --d;
-  while (d < n_out && axis_map_u(d, r, n_in).i0 < t) ++d;
-  return d;
-}
 
 // grid = (ceil(W/64), ceil(H/16), planes); block 256 = 16 rows x 16 strips of 4 pixels
 __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int h,

@@ -152,7 +152,8 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 
 // ---- output transform: y tile = act(scale[c] * (A^T m A) + bias[c]), m[k] = M[k][t][c]; act = ReLU or identity ---
 template <int M, int VEC>
-__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mx, const float* __restrict__ scale,
+__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mx, const float* __restrict__ addend,
+                                                          const float* __restrict__ scale,
                                                           const float* __restrict__ bias, int relu,
                                                           float* __restrict__ y, int C, int H, int W, int nTh, int nTw,
                                                           int64_t T, int64_t total) {
@@ -197,6 +198,12 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
         bool first = true;
 #pragma unroll
         for (int j = 0; j < A; ++j) axpy<VEC>(wino_at(M, q, j), tmp[p][j], o, first);
+        if (addend && yy < H && xx < W) {  // contribution of the coarse inputs (M6), before scale / shift
+          float ad[VEC];
+          vload<VEC>(addend + (int64_t)b * H * W * C + ((int64_t)yy * W + xx) * C + (int64_t)cg * VEC, ad);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) o[e] += ad[e];
+        }
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           o[e] = scale ? fmaf(o[e], sv[e], bv[e]) : o[e] + bv[e];
@@ -285,20 +292,20 @@ extern "C" int sea_wino_input_transform(const float* x, int64_t x_pixel_stride, 
   SEA_RETURN_LAST();
 }
 
-extern "C" int sea_wino_output_transform(const float* Mx, const float* scale, const float* bias, int relu, float* y, int B,
-                                         int C, int H, int W, int m, void* stream) {
+extern "C" int sea_wino_output_transform(const float* Mx, const float* addend, const float* scale, const float* bias,
+                                         int relu, float* y, int B, int C, int H, int W, int m, void* stream) {
   int nTh, nTw;
   int64_t T;
   SEA_CHECK_ARG(Mx && y && wino_dims(B, C, H, W, m, 4, &nTh, &nTw, &T));
-  SEA_CHECK_ARG(((((uintptr_t)Mx) | ((uintptr_t)y)) & 15) == 0);
+  SEA_CHECK_ARG(((((uintptr_t)Mx) | ((uintptr_t)y) | ((uintptr_t)addend)) & 15) == 0);
   if (m == 2) {
     const int64_t total = T * (C / 4);
     hipLaunchKernelGGL((wino_output_kernel<2, 4>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, Mx,
-                       scale, bias, relu, y, C, H, W, nTh, nTw, T, total);
+                       addend, scale, bias, relu, y, C, H, W, nTh, nTw, T, total);
   } else {
     const int64_t total = T * (C / 2);
     hipLaunchKernelGGL((wino_output_kernel<4, 2>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, Mx,
-                       scale, bias, relu, y, C, H, W, nTh, nTw, T, total);
+                       addend, scale, bias, relu, y, C, H, W, nTh, nTw, T, total);
   }
   SEA_RETURN_LAST();
 }

@@ -55,7 +55,10 @@ _SIGS = {
     "sea_wino_tiles": (_i64, [_i, _i, _i, _i]),
     "sea_wino_input_transform": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sea_wino_filter_transform": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
-    "sea_wino_output_transform": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sea_wino_output_transform": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sea_tap_gather_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "sea_tap_gather_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "sea_gate_scale": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _vp]),
     "sea_upsample_bilinear_nhwc_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i64, _vp]),
     "sea_upsample_bilinear_nhwc_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i64, _vp]),
 }
@@ -379,6 +382,47 @@ def upsample_bilinear_backward_cl(gy, in_size):
     return gx
 
 
+# ------------------------------------------------------------------------------------------------ M6
+def tap_gather(G, size, extra=None):
+    """G (B,h,w,9,C) coarse per-tap maps -> (B,C,H,W) channels_last: sum over the 3x3 taps of the shifted
+    bilinear up-samplings (added to ``extra`` in place when given)."""
+    _dev(G, extra)
+    B, h, w, nine, Cc = G.shape
+    H, W = int(size[0]), int(size[1])
+    if nine != 9:
+        raise SeaNativeError("tap_gather: G must be (B,h,w,9,C)")
+    acc = extra is not None
+    if extra is None:
+        extra = torch.empty(B, Cc, H, W, dtype=torch.float32, device=G.device, memory_format=torch.channels_last)
+    elif tuple(extra.shape) != (B, Cc, H, W) or cl_pixel_stride(extra) != Cc:
+        raise SeaNativeError("tap_gather: extra must be a dense channels_last (B,C,H,W) float32 tensor")
+    _check(lib().sea_tap_gather_fwd(_p(_f32c(G)), _p(extra), int(acc), B, Cc, h, w, H, W, _stream()), "sea_tap_gather_fwd")
+    return extra
+
+
+def tap_gather_backward(gz, coarse_size):
+    """gz dense channels_last (B,C,H,W) -> dG (B,h,w,9,C): the adjoint of tap_gather."""
+    _dev(gz)
+    B, Cc, H, W = gz.shape
+    if cl_pixel_stride(gz) != Cc:
+        raise SeaNativeError("tap_gather_backward: dense channels_last float32 gradient expected")
+    h, w = int(coarse_size[0]), int(coarse_size[1])
+    dG = torch.empty(B, h, w, 9, Cc, dtype=torch.float32, device=gz.device)
+    _check(lib().sea_tap_gather_bwd(_p(gz), _p(dG), B, Cc, h, w, H, W, _stream()), "sea_tap_gather_bwd")
+    return dG
+
+
+def gate_scale(g, gate, scale):
+    """gate > 0 ? g * scale[c] : 0 for dense channels_last (B,C,H,W) tensors."""
+    _dev(g, gate, scale)
+    B, Cc, H, W = g.shape
+    if cl_pixel_stride(g) != Cc or cl_pixel_stride(gate) != Cc or gate.shape != g.shape or scale.numel() != Cc:
+        raise SeaNativeError("gate_scale: dense channels_last float32 tensors of one shape expected")
+    out = torch.empty_like(g)
+    _check(lib().sea_gate_scale(_p(g), _p(gate), _p(_f32c(scale)), _p(out), B * H * W, Cc, _stream()), "sea_gate_scale")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ M5
 def layernorm(x, weight, bias, eps: float):
     """LayerNorm over the last dim of a contiguous fp32 tensor; returns (y, mean, rstd)."""
@@ -417,11 +461,13 @@ def wino_filter(weight, m: int, flip: bool):
     return U
 
 
-def wino_conv3x3_cl(x, U, m: int, bias=None, scale=None, relu: bool = False, gate=None, gate_scale=None):
+def wino_conv3x3_cl(x, U, m: int, bias=None, scale=None, relu: bool = False, gate=None, gate_scale=None,
+                    addend=None):
     """3x3 / stride 1 / pad 1 convolution of a channels_last (B,Cin,H,W) tensor (or channel slice) with Winograd-domain
     filters U (A*A, Cin, Cout); returns channels_last (B,Cout,H,W) = act(scale[c] * conv + bias[c]).
-    ``gate`` (same shape as x) / ``gate_scale``: the input is read as gate > 0 ? x * gate_scale[c] : 0."""
-    _dev(x, U, bias, scale, gate, gate_scale)
+    ``gate`` (same shape as x) / ``gate_scale``: the input is read as gate > 0 ? x * gate_scale[c] : 0.
+    ``addend`` (dense channels_last (B,Cout,H,W)) is added to the convolution before scale / bias / act."""
+    _dev(x, U, bias, scale, gate, gate_scale, addend)
     B, Cin, H, W = x.shape
     A2, Ci, Cout = U.shape
     xps = cl_pixel_stride(x)  # a channel slice of a wider channels_last tensor is read in place
@@ -440,7 +486,10 @@ def wino_conv3x3_cl(x, U, m: int, bias=None, scale=None, relu: bool = False, gat
     Mx = torch.bmm(V, U)  # (A*A) independent fp32 GEMMs: hipBLASLt strided-batched
     del V
     y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-    _check(L.sea_wino_output_transform(_p(Mx), _p(scale), _p(bias), int(relu), _p(y), B, Cout, H, W, m, _stream()),
+    if addend is not None and (tuple(addend.shape) != (B, Cout, H, W) or cl_pixel_stride(addend) != Cout):
+        raise SeaNativeError("wino_conv3x3_cl: addend must be a dense channels_last (B,Cout,H,W) float32 tensor")
+    _check(L.sea_wino_output_transform(_p(Mx), _p(addend), _p(scale), _p(bias), int(relu), _p(y), B, Cout, H, W, m,
+                                       _stream()),
            "sea_wino_output_transform")
     return y
 

@@ -321,7 +321,7 @@ class ConvNeXt(nn.Module):
 # 0.25; unit-test error bounds vs float64: 2e-5 (2, same as direct fp32) / 3e-4 (4).  The config-#1 reference
 # parity test (tests/test_config1_parity.py) passes at the same tolerances for all three settings.
 WINOGRAD_TILE = int(os.environ.get("SEA_WINOGRAD", "4"))
-WINOGRAD_MIN_PIXELS = 32 * 32  # below this MIOpen's own kernels win (few tiles per GEMM)
+WINOGRAD_MIN_PIXELS = 16 * 16  # the PSP bottleneck (2816 -> 512 at 16x16) still wins 3x; below, few tiles per GEMM
 
 
 class _WinoConv3x3(torch.autograd.Function):
@@ -555,6 +555,87 @@ def _up_cat(ts, size):
     return torch.cat([t if tuple(t.shape[2:]) == size else _up(t, size) for t in ts], dim=1)
 
 
+# M6: inputs of the FPN bottleneck that are >= x3 up-samplings are not up-sampled at all: their nine 3x3 taps run
+# as one GEMM at the coarse resolution (channel mixing commutes with bilinear interpolation) and a gather adds the
+# shifted interpolations into the Winograd output transform.  ConvNeXt-T, B=8, 512x512: the Winograd GEMM of the
+# bottleneck shrinks from K=2048 to K=1024 input channels.
+USE_FUSED_FPN_BOTTLENECK = True
+LOWRES_MIN_FACTOR = 3.0
+
+
+class _FpnBottleneck(torch.autograd.Function):
+    """relu(bn(conv3x3(cat([f0, up(f1), ..., up(fn)])))) for frozen weights / eval-mode BatchNorm, input grads only."""
+
+    @staticmethod
+    def forward(ctx, m, cache, weight, scale, shift, *fs):
+        from .. import _native as N
+        B, (H, W), Cout = fs[0].shape[0], fs[0].shape[2:], weight.shape[0]
+        chans = [f.shape[1] for f in fs]
+        offs = [sum(chans[:i]) for i in range(len(fs))]
+        hi = [i for i, f in enumerate(fs) if i == 0 or H / f.shape[2] < LOWRES_MIN_FACTOR or W / f.shape[3] < LOWRES_MIN_FACTOR]
+        lo = [i for i in range(len(fs)) if i not in hi]
+        key = (weight.data_ptr(), weight._version, m, tuple(hi), tuple(chans))
+        if cache.get("fpn_key") != key:
+            w_hi = torch.cat([weight[:, offs[i]:offs[i] + chans[i]] for i in hi], 1).contiguous()
+            cache.update(fpn_key=key, fpn_fwd=N.wino_filter(w_hi, m, False), fpn_bwd=N.wino_filter(w_hi, m, True),
+                         fpn_lo=[weight[:, offs[i]:offs[i] + chans[i]].permute(2, 3, 0, 1).reshape(9 * Cout, chans[i])
+                                 .contiguous() for i in lo])  # rows (tap, cout): F.linear -> (B,h,w,9*Cout)
+        buf = torch.empty(B, sum(chans[i] for i in hi), H, W, dtype=torch.float32, device=fs[0].device,
+                          memory_format=_CL)
+        off = 0
+        for i in hi:
+            sl = buf[:, off:off + chans[i]]
+            if tuple(fs[i].shape[2:]) == (H, W):
+                sl.copy_(fs[i])
+            else:
+                N.upsample_bilinear_cl(_dense_cl(fs[i]), (H, W), out=sl)
+            off += chans[i]
+        extra = None
+        for j, i in enumerate(lo):
+            f = _dense_cl(fs[i])
+            G = F.linear(f.permute(0, 2, 3, 1), cache["fpn_lo"][j]).view(B, f.shape[2], f.shape[3], 9, Cout)
+            extra = N.tap_gather(G, (H, W), extra)
+        y = N.wino_conv3x3_cl(buf, cache["fpn_fwd"], m, bias=shift, scale=scale, relu=True, addend=extra)
+        ctx.save_for_backward(y, scale)
+        ctx.cache, ctx.m, ctx.hi, ctx.lo, ctx.chans = cache, m, hi, lo, chans
+        ctx.shapes = [tuple(f.shape) for f in fs]
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .. import _native as N
+        y, scale = ctx.saved_tensors
+        cache, chans, shapes = ctx.cache, ctx.chans, ctx.shapes
+        B, _, H, W = y.shape
+        gz = N.gate_scale(_dense_cl(gy), y, scale)
+        grads = [None] * len(shapes)
+        if any(ctx.needs_input_grad[5 + i] for i in ctx.hi):
+            gbuf = N.wino_conv3x3_cl(gz, cache["fpn_bwd"], ctx.m)
+            off = 0
+            for i in ctx.hi:
+                sl = gbuf[:, off:off + chans[i]]
+                off += chans[i]
+                if ctx.needs_input_grad[5 + i]:
+                    grads[i] = sl if shapes[i][2:] == (H, W) else N.upsample_bilinear_backward_cl(sl, shapes[i][2:])
+        for j, i in enumerate(ctx.lo):
+            if ctx.needs_input_grad[5 + i]:
+                h, w = shapes[i][2:]
+                dG = N.tap_gather_backward(gz, (h, w))
+                grads[i] = torch.mm(dG.view(B * h * w, -1), cache["fpn_lo"][j]).view(B, h, w, chans[i]).permute(0, 3, 1, 2)
+        return (None, None, None, None, None, *grads)
+
+
+def _fpn_fusable(mod, outs):
+    bn = mod.batch_norm
+    size = tuple(outs[0].shape[2:])
+    return (USE_FUSED_FPN_BOTTLENECK and _wino_ok(mod.conv, outs[0]) and mod.conv.bias is None and not bn.training
+            and bn.track_running_stats and isinstance(mod.activation, nn.ReLU)
+            and not any(p.requires_grad for p in bn.parameters()) and _cl_fusable(outs, size)
+            and mod.conv.in_channels == sum(o.shape[1] for o in outs)
+            and any(size[0] / o.shape[2] >= LOWRES_MIN_FACTOR and size[1] / o.shape[3] >= LOWRES_MIN_FACTOR
+                    for o in outs[1:]))
+
+
 class PyramidPooling(nn.Module):
     """Children "0".."3", each Sequential-like [AdaptiveAvgPool2d(s), ConvModule] with children "0","1"."""
 
@@ -596,7 +677,15 @@ class UperNetHead(nn.Module):
         for i in range(len(lat) - 1, 0, -1):
             lat[i - 1] = _up_add(lat[i], lat[i - 1])
         outs = [self.fpn_convs[i](lat[i]) for i in range(len(lat) - 1)] + [lat[-1]]
-        return self.classifier(self.fpn_bottleneck(_up_cat(outs, outs[0].shape[2:])))
+        neck = self.fpn_bottleneck
+        if _fpn_fusable(neck, outs):
+            if not hasattr(neck, "_wino_cache"):
+                object.__setattr__(neck, "_wino_cache", {})
+            scale, shift = _folded_bn(neck.batch_norm, None, neck._wino_cache)
+            y = _FpnBottleneck.apply(WINOGRAD_TILE, neck._wino_cache, neck.conv.weight, scale, shift, *outs)
+        else:
+            y = neck(_up_cat(outs, outs[0].shape[2:]))
+        return self.classifier(y)
 
 
 class UperNetFCNHead(nn.Module):

@@ -506,6 +506,77 @@ def test_upernet_head_with_and_without_hip_upsample(N):
         assert ((outs[k][1] - outs[2][1]).abs() > 1e-3 * gmax).float().mean() < 0.01
 
 
+# ------------------------------------------------------------------------------------------------ M6
+@pytest.mark.parametrize("case", [(2, 8, 12, 4, 4, 16, 16), (1, 16, 8, 3, 5, 24, 40), (2, 4, 4, 1, 1, 8, 8),
+                                  (1, 8, 8, 5, 4, 17, 13), (1, 32, 64, 8, 8, 64, 64)])
+def test_tap_gather_is_conv3x3_of_the_upsampled_input(N, case):
+    """conv3x3(up(f)) == tap_gather(f @ W) (channel mixing commutes with bilinear interpolation), and the
+    backward kernel is the exact adjoint."""
+    import torch.nn.functional as F
+    B, Cin, Cout, h, w, H, W = case
+    g = torch.Generator().manual_seed(Cin + H)
+    f = torch.randn(B, Cin, h, w, generator=g)
+    wt = torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)
+    gz = torch.randn(B, Cout, H, W, generator=g)
+    cl = torch.channels_last
+    fd = f.double().requires_grad_(True)
+    ref = F.conv2d(F.interpolate(fd, size=(H, W), mode="bilinear", align_corners=False), wt.double(), padding=1)
+    (gf_ref,) = torch.autograd.grad(ref, fd, gz.double())
+    Wl = dev(wt).permute(2, 3, 0, 1).reshape(9 * Cout, Cin).contiguous()
+    G = F.linear(dev(f).permute(0, 2, 3, 1).contiguous(), Wl).view(B, h, w, 9, Cout)
+    extra = N.tap_gather(G, (H, W))
+    assert extra.is_contiguous(memory_format=cl) or min(H, W) == 1
+    torch.testing.assert_close(extra.cpu().double(), ref.detach(), rtol=2e-5, atol=2e-5)
+    twice = N.tap_gather(G, (H, W), extra.clone())  # accumulate
+    torch.testing.assert_close(twice, 2 * extra, rtol=1e-6, atol=1e-6)
+    dG = N.tap_gather_backward(dev(gz).contiguous(memory_format=cl), (h, w))
+    gf = torch.mm(dG.view(B * h * w, -1), Wl).view(B, h, w, Cin).permute(0, 3, 1, 2)
+    torch.testing.assert_close(gf.cpu().double(), gf_ref, rtol=1e-4, atol=1e-4)
+    # adjoint identity <tap_gather(G), gz> == <G, tap_gather_backward(gz)>
+    lhs = (extra.double() * dev(gz).double()).sum().item()
+    rhs = (G.double() * dG.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs))
+    gate = torch.randn(B, Cout, H, W, generator=g)
+    sc = torch.rand(Cout, generator=g) + 0.5
+    out = N.gate_scale(dev(gz).contiguous(memory_format=cl), dev(gate).contiguous(memory_format=cl), dev(sc))
+    torch.testing.assert_close(out.cpu(), torch.where(gate > 0, gz * sc[None, :, None, None], torch.zeros(())),
+                               rtol=1e-6, atol=1e-6)
+
+
+def test_fused_fpn_bottleneck_matches_the_reference_composition(N):
+    """UperNet head with the coarse FPN inputs folded into coarse GEMMs + gather (M6) against the same head with
+    Winograd off and M6 off (MIOpen + ATen composition): logits and input gradients."""
+    from semseg.models import convnext_upernet as M
+    torch.manual_seed(0)
+    model = M.UperNetForSemanticSegmentation("ConvNeXt-T_CVST", 21, None).cuda().eval()
+    for mod in model.modules():  # non-trivial BatchNorm statistics
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.normal_(0, 0.1)
+            mod.running_var.uniform_(0.5, 1.5)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    x = torch.rand(2, 3, 256, 192, device="cuda")
+    outs, tile = [], M.WINOGRAD_TILE
+    try:
+        for fused, t in ((True, 4), (True, 2), (False, 4), (False, 0)):
+            M.USE_FUSED_FPN_BOTTLENECK, M.WINOGRAD_TILE = fused, t
+            xi = x.clone().requires_grad_(True)
+            y = model(xi)
+            assert (type(y.grad_fn).__name__ != "") and y.is_contiguous()
+            (gx,) = torch.autograd.grad((y * y).sum(), xi)
+            outs.append((y.detach(), gx))
+            cache = getattr(model.decode_head.fpn_bottleneck, "_wino_cache", {})
+            assert ("fpn_key" in cache) == fused or not fused  # the fused path really ran
+            if not fused:
+                cache.pop("fpn_key", None)
+    finally:
+        M.USE_FUSED_FPN_BOTTLENECK, M.WINOGRAD_TILE = True, tile
+    ref_y, ref_g = outs[3]
+    for k in range(3):
+        assert (outs[k][0] - ref_y).abs().max() <= 2e-4 * ref_y.abs().max()
+        assert (outs[k][1] - ref_g).norm() <= 2e-3 * ref_g.norm()
+
+
 # ------------------------------------------------------------------------------------------------ M5
 @pytest.mark.parametrize("shape", [(2, 16, 16, 48), (3, 7, 5, 96), (1, 9, 192), (5, 384), (2, 3, 768), (7, 4),
                                    (3, 1024), (11, 100), (1, 200, 300, 96)])

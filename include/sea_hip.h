@@ -241,7 +241,9 @@ int sea_upsample_bilinear_nhwc_bwd(const float* gy, float* gx, int B, int C, int
  *   T = sea_wino_tiles(B, H, W, m) = B * ceil(H/m) * ceil(W/m),  A = m + 2
  *   sea_wino_input_transform :  x (B,H,W,C) -> V (A*A, T, C); x may be a channel slice of a wider NHWC
  *                               tensor (x_pixel_stride floats between pixels, >= C, % 4 == 0: the gradient
- *                               of a concatenation buffer is read in place); with gate (B,H,W,C, dense) the tiles are loaded
+ *                               of a concatenation buffer is read in place), and V a channel slice of a
+ *                               wider (A*A, T, v_tile_stride) tensor (inputs that the reference concatenates
+ *                               are transformed side by side, never concatenated); with gate (B,H,W,C, dense) the tiles are loaded
  *                               as  gate > 0 ? x * scale[c] : 0  (scale NULL = 1): the backward of the
  *                               fused epilogue below, applied to the incoming output gradient
  *   sea_wino_filter_transform:  w (Cout,Cin,3,3) -> U (A*A, Cin, Cout)             (flip = 0, forward)
@@ -253,7 +255,7 @@ int sea_upsample_bilinear_nhwc_bwd(const float* gy, float* gx, int B, int C, int
  * C % 4 == 0, 16-byte aligned pointers. */
 int64_t sea_wino_tiles(int B, int H, int W, int m);
 int sea_wino_input_transform(const float* x, int64_t x_pixel_stride, const float* gate, const float* scale,
-                             float* V, int B, int C, int H, int W, int m, void* stream);
+                             float* V, int64_t v_tile_stride, int B, int C, int H, int W, int m, void* stream);
 int sea_wino_filter_transform(const float* w, float* U, int Cout, int Cin, int m, int flip, void* stream);
 int sea_wino_output_transform(const float* M, const float* addend, const float* scale, const float* bias,
                               int relu, float* y, int B, int C, int H, int W, int m, void* stream);

@@ -16,48 +16,80 @@
 
 namespace sea {
 
+// One lane = (4x4 block of output pixels, 4 channels).  For an up-sampling factor >= 3 the four sample positions
+// of one tap row / column touch at most 3 coarse rows / columns, so per tap a 3x3 coarse window (9 loads) feeds all
+// 16 outputs through separable weights: 81 loads per 16 outputs instead of 36 per output (the plain gather was
+// bound by L2 bandwidth at 16 TB/s of corner re-reads).
+constexpr int kTB = 4;
+
 __global__ __launch_bounds__(256) void tap_gather_fwd_kernel(const float4* __restrict__ G, float4* __restrict__ extra,
                                                              int accumulate, int CG, int h, int w, int H, int W, float rh,
-                                                             float rw, int64_t total) {
+                                                             float rw, int nBh, int nBw, int64_t total) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int cg = (int)(i % CG);
     int64_t p = i / CG;
-    const int X = (int)(p % W);
-    p /= W;
-    const int Y = (int)(p % H);
-    const int b = (int)(p / H);
-    AxisMapU my[3], mx[3];
-    bool vy[3], vx[3];
+    const int bx = (int)(p % nBw);
+    p /= nBw;
+    const int by = (int)(p % nBh);
+    const int b = (int)(p / nBh);
+    const int Y0 = by * kTB, X0 = bx * kTB;
+    float4 acc[kTB][kTB];
+    float4* eb = extra + (int64_t)b * H * W * CG + cg;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const int P = Y + a - 1, Q = X + a - 1;
-      vy[a] = P >= 0 && P < H;
-      vx[a] = Q >= 0 && Q < W;
-      my[a] = axis_map_u(vy[a] ? P : Y, rh, h);
-      mx[a] = axis_map_u(vx[a] ? Q : X, rw, w);
-    }
-    float4 acc = accumulate ? extra[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int py = 0; py < kTB; ++py)
+#pragma unroll
+      for (int px = 0; px < kTB; ++px)
+        acc[py][px] = (accumulate && Y0 + py < H && X0 + px < W) ? eb[((int64_t)(Y0 + py) * W + X0 + px) * CG]
+                                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4* Gb = G + (int64_t)b * h * w * 9 * CG + cg;
+#pragma unroll 1  // one tap at a time: 9 loads in flight, ~150 VGPRs (fully unrolled the 81 loads spill)
+    for (int tap = 0; tap < 9; ++tap) {
+      const int a = tap / 3, bq = tap - a * 3;
+      // wy[py][k] = weight of coarse row ib + k for the sample row P = Y0+py+a-1 (0 outside the image); same for columns
+      const int ib = axis_map_u(min(max(Y0 + a - 1, 0), H - 1), rh, h).i0;
+      const int jb = axis_map_u(min(max(X0 + bq - 1, 0), W - 1), rw, w).i0;
+      float wy[kTB][3], wx[kTB][3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      if (!vy[a]) continue;
-      const float ly = my[a].lam, uy = 1.f - ly;
+      for (int q = 0; q < kTB; ++q) {
+        const int P = Y0 + q + a - 1, Q = X0 + q + bq - 1;
+        const bool oky = P >= 0 && P < H, okx = Q >= 0 && Q < W;
 #pragma unroll
-      for (int bq = 0; bq < 3; ++bq) {
-        if (!vx[bq]) continue;
-        const int tap = a * 3 + bq;
-        const float lx = mx[bq].lam, ux = 1.f - lx;
-        const float4 v00 = Gb[(((int64_t)my[a].i0 * w + mx[bq].i0) * 9 + tap) * CG];
-        const float4 v01 = Gb[(((int64_t)my[a].i0 * w + mx[bq].i1) * 9 + tap) * CG];
-        const float4 v10 = Gb[(((int64_t)my[a].i1 * w + mx[bq].i0) * 9 + tap) * CG];
-        const float4 v11 = Gb[(((int64_t)my[a].i1 * w + mx[bq].i1) * 9 + tap) * CG];
-        acc.x += uy * (ux * v00.x + lx * v01.x) + ly * (ux * v10.x + lx * v11.x);
-        acc.y += uy * (ux * v00.y + lx * v01.y) + ly * (ux * v10.y + lx * v11.y);
-        acc.z += uy * (ux * v00.z + lx * v01.z) + ly * (ux * v10.z + lx * v11.z);
-        acc.w += uy * (ux * v00.w + lx * v01.w) + ly * (ux * v10.w + lx * v11.w);
+        for (int k = 0; k < 3; ++k) {
+          wy[q][k] = oky ? axis_coef(P, ib + k, rh, h) : 0.f;
+          wx[q][k] = okx ? axis_coef(Q, jb + k, rw, w) : 0.f;
+        }
+      }
+      float4 g[3][3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+          g[k][l] = Gb[(((int64_t)min(ib + k, h - 1) * w + min(jb + l, w - 1)) * 9 + tap) * CG];
+#pragma unroll
+      for (int py = 0; py < kTB; ++py) {
+        float4 t[3];
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+          t[l].x = wy[py][0] * g[0][l].x + wy[py][1] * g[1][l].x + wy[py][2] * g[2][l].x;
+          t[l].y = wy[py][0] * g[0][l].y + wy[py][1] * g[1][l].y + wy[py][2] * g[2][l].y;
+          t[l].z = wy[py][0] * g[0][l].z + wy[py][1] * g[1][l].z + wy[py][2] * g[2][l].z;
+          t[l].w = wy[py][0] * g[0][l].w + wy[py][1] * g[1][l].w + wy[py][2] * g[2][l].w;
+        }
+#pragma unroll
+        for (int px = 0; px < kTB; ++px) {
+          const float c0 = wx[px][0], c1 = wx[px][1], c2 = wx[px][2];
+          acc[py][px].x += c0 * t[0].x + c1 * t[1].x + c2 * t[2].x;
+          acc[py][px].y += c0 * t[0].y + c1 * t[1].y + c2 * t[2].y;
+          acc[py][px].z += c0 * t[0].z + c1 * t[1].z + c2 * t[2].z;
+          acc[py][px].w += c0 * t[0].w + c1 * t[1].w + c2 * t[2].w;
+        }
       }
     }
-    extra[i] = acc;
+#pragma unroll
+    for (int py = 0; py < kTB; ++py)
+#pragma unroll
+      for (int px = 0; px < kTB; ++px)
+        if (Y0 + py < H && X0 + px < W) eb[((int64_t)(Y0 + py) * W + X0 + px) * CG] = acc[py][px];
   }
 }
 
@@ -140,12 +172,15 @@ using namespace sea;
 // G (B,h,w,9,C) coarse per-tap maps -> extra (B,H,W,C) (+)= sum over the 3x3 taps of the shifted up-samplings
 extern "C" int sea_tap_gather_fwd(const float* G, float* extra, int accumulate, int B, int C, int h, int w, int H, int W,
                                   void* stream) {
-  SEA_CHECK_ARG(G && extra && B > 0 && C > 0 && (C % 4) == 0 && h > 0 && w > 0 && H >= h && W >= w);
+  SEA_CHECK_ARG(G && extra && B > 0 && C > 0 && (C % 4) == 0 && h > 0 && w > 0);
+  // the 3x3 coarse window per tap covers 4 consecutive sample positions only for factors >= 3
+  SEA_CHECK_ARG((int64_t)H >= 3 * (int64_t)h && (int64_t)W >= 3 * (int64_t)w);
   SEA_CHECK_ARG(((((uintptr_t)G) | ((uintptr_t)extra)) & 15) == 0);
-  const int64_t total = (int64_t)B * H * W * (C / 4);
+  const int nBh = (H + kTB - 1) / kTB, nBw = (W + kTB - 1) / kTB;
+  const int64_t total = (int64_t)B * nBh * nBw * (C / 4);
   hipLaunchKernelGGL(tap_gather_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const float4*)G, (float4*)extra, accumulate, C / 4, h, w, H, W, (float)h / (float)H,
-                     (float)w / (float)W, total);
+                     (float)w / (float)W, nBh, nBw, total);
   SEA_RETURN_LAST();
 }
 

@@ -88,7 +88,7 @@ template <int M, int VEC>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, const float* __restrict__ gate,
                                                          const float* __restrict__ scale, float* __restrict__ V, int C,
                                                          int H, int W, int nTh, int nTw, int64_t T, int64_t total,
-                                                         int64_t xps) {
+                                                         int64_t xps, int64_t vts) {
   constexpr int A = M + 2;
   const int CG = C / VEC;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
         for (int k = 0; k < A; ++k) axpy<VEC>(wino_bt(M, i, k), d[k][j], tmp[i][j], first);
       }
     // columns: v = tmp B, streamed out as soon as each element is ready
-    float* vb = V + t * C + (int64_t)cg * VEC;
+    float* vb = V + t * vts + (int64_t)cg * VEC;  // V may be a channel slice of a wider (A*A, T, vts) tensor
 #pragma unroll
     for (int i = 0; i < A; ++i)
 #pragma unroll
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
         bool first = true;
 #pragma unroll
         for (int k = 0; k < A; ++k) axpy<VEC>(wino_bt(M, j, k), tmp[i][k], v, first);
-        vstore<VEC>(vb + (int64_t)(i * A + j) * T * C, v);
+        vstore<VEC>(vb + (int64_t)(i * A + j) * T * vts, v);
       }
   }
 }
@@ -274,20 +274,22 @@ extern "C" int64_t sea_wino_tiles(int B, int H, int W, int m) {
 }
 
 extern "C" int sea_wino_input_transform(const float* x, int64_t x_pixel_stride, const float* gate, const float* scale,
-                                        float* V, int B, int C, int H, int W, int m, void* stream) {
+                                        float* V, int64_t v_tile_stride, int B, int C, int H, int W, int m,
+                                        void* stream) {
   int nTh, nTw;
   int64_t T;
   SEA_CHECK_ARG(x && V && wino_dims(B, C, H, W, m, 4, &nTh, &nTw, &T));
   SEA_CHECK_ARG(x_pixel_stride >= C && (x_pixel_stride % 4) == 0);
+  SEA_CHECK_ARG(v_tile_stride >= C && (v_tile_stride % 4) == 0);
   SEA_CHECK_ARG(((((uintptr_t)x) | ((uintptr_t)V) | ((uintptr_t)gate)) & 15) == 0);
   if (m == 2) {
     const int64_t total = T * (C / 4);
     hipLaunchKernelGGL((wino_input_kernel<2, 4>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, gate,
-                       scale, V, C, H, W, nTh, nTw, T, total, x_pixel_stride);
+                       scale, V, C, H, W, nTh, nTw, T, total, x_pixel_stride, v_tile_stride);
   } else {
     const int64_t total = T * (C / 2);
     hipLaunchKernelGGL((wino_input_kernel<4, 2>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, gate,
-                       scale, V, C, H, W, nTh, nTw, T, total, x_pixel_stride);
+                       scale, V, C, H, W, nTh, nTw, T, total, x_pixel_stride, v_tile_stride);
   }
   SEA_RETURN_LAST();
 }

@@ -53,7 +53,7 @@ _SIGS = {
     "sea_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _vp]),
     "sea_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp]),
     "sea_wino_tiles": (_i64, [_i, _i, _i, _i]),
-    "sea_wino_input_transform": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sea_wino_input_transform": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
     "sea_wino_filter_transform": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "sea_wino_output_transform": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "sea_tap_gather_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -463,34 +463,40 @@ def wino_filter(weight, m: int, flip: bool):
 
 def wino_conv3x3_cl(x, U, m: int, bias=None, scale=None, relu: bool = False, gate=None, gate_scale=None,
                     addend=None):
-    """3x3 / stride 1 / pad 1 convolution of a channels_last (B,Cin,H,W) tensor (or channel slice) with Winograd-domain
-    filters U (A*A, Cin, Cout); returns channels_last (B,Cout,H,W) = act(scale[c] * conv + bias[c]).
+    """3x3 / stride 1 / pad 1 convolution of a channels_last (B,Cin,H,W) tensor (or channel slice) -- or of the
+    channel concatenation of a list of such tensors, which is never materialised -- with Winograd-domain filters
+    U (A*A, Cin, Cout); returns channels_last (B,Cout,H,W) = act(scale[c] * (conv + addend) + bias[c]).
     ``gate`` (same shape as x) / ``gate_scale``: the input is read as gate > 0 ? x * gate_scale[c] : 0.
     ``addend`` (dense channels_last (B,Cout,H,W)) is added to the convolution before scale / bias / act."""
-    _dev(x, U, bias, scale, gate, gate_scale, addend)
-    B, Cin, H, W = x.shape
+    xs = list(x) if isinstance(x, (list, tuple)) else [x]
+    _dev(*xs, U, bias, scale, gate, gate_scale, addend)
+    B, _, H, W = xs[0].shape
+    Cin = sum(t.shape[1] for t in xs)
     A2, Ci, Cout = U.shape
-    xps = cl_pixel_stride(x)  # a channel slice of a wider channels_last tensor is read in place
-    if xps is None or Ci != Cin or A2 != (m + 2) ** 2 or Cout % 4:
-        raise SeaNativeError("wino_conv3x3_cl: channels_last float32 input (or channel slice) and matching filters expected")
-    if gate is not None and (gate.shape != x.shape or cl_pixel_stride(gate) != Cin):
-        raise SeaNativeError("wino_conv3x3_cl: gate must match the input's shape and layout")
+    strides = [cl_pixel_stride(t) for t in xs]  # channel slices of wider channels_last tensors are read in place
+    if (any(p is None for p in strides) or any(tuple(t.shape[2:]) != (H, W) or t.shape[0] != B for t in xs) or Ci != Cin
+            or A2 != (m + 2) ** 2 or Cout % 4):
+        raise SeaNativeError("wino_conv3x3_cl: channels_last float32 inputs (or channel slices) and matching filters expected")
+    if gate is not None and (len(xs) != 1 or gate.shape != xs[0].shape or cl_pixel_stride(gate) != Cin):
+        raise SeaNativeError("wino_conv3x3_cl: gate must match the (single) input's shape and layout")
     for v, n in ((bias, Cout), (scale, Cout), (gate_scale, Cin)):
         if v is not None and (v.dtype != torch.float32 or v.numel() != n or not v.is_contiguous()):
             raise SeaNativeError("wino_conv3x3_cl: per-channel vectors must be contiguous float32 of the channel count")
     L = lib()
     T = L.sea_wino_tiles(B, H, W, m)
-    V = torch.empty(A2, T, Cin, dtype=torch.float32, device=x.device)
-    _check(L.sea_wino_input_transform(_p(x), xps, _p(gate), _p(gate_scale), _p(V), B, Cin, H, W, m, _stream()),
-           "sea_wino_input_transform")
+    V = torch.empty(A2, T, Cin, dtype=torch.float32, device=xs[0].device)
+    off = 0
+    for t, xps in zip(xs, strides):
+        _check(L.sea_wino_input_transform(_p(t), xps, _p(gate), _p(gate_scale), V.data_ptr() + 4 * off, Cin, B, t.shape[1],
+                                          H, W, m, _stream()), "sea_wino_input_transform")
+        off += t.shape[1]
     Mx = torch.bmm(V, U)  # (A*A) independent fp32 GEMMs: hipBLASLt strided-batched
     del V
-    y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=xs[0].device, memory_format=torch.channels_last)
     if addend is not None and (tuple(addend.shape) != (B, Cout, H, W) or cl_pixel_stride(addend) != Cout):
         raise SeaNativeError("wino_conv3x3_cl: addend must be a dense channels_last (B,Cout,H,W) float32 tensor")
     _check(L.sea_wino_output_transform(_p(Mx), _p(addend), _p(scale), _p(bias), int(relu), _p(y), B, Cout, H, W, m,
-                                       _stream()),
-           "sea_wino_output_transform")
+                                       _stream()), "sea_wino_output_transform")
     return y
 
 

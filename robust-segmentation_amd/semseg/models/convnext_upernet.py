@@ -413,8 +413,11 @@ class ConvModule(nn.Module):
         if cache.get("pw_key") != key:
             with torch.no_grad():
                 cache.update(pw_key=key, pw_w=(w.view(w.shape[0], -1) * scale[:, None]).contiguous())
-        y = F.linear(x.permute(0, 2, 3, 1), cache["pw_w"], shift)  # (B,H,W,Cout)
-        return F.relu(y, inplace=True).permute(0, 3, 1, 2)
+        B, _, H, W = x.shape
+        # 2-D GEMM on the (pixels, Cin) view; ReLU in place on the GEMM's own output (an in-place op on a VIEW of it
+        # would make autograd clone / copy whole tensors in CopySlices)
+        y = torch.relu_(torch.addmm(shift, x.permute(0, 2, 3, 1).reshape(B * H * W, -1), cache["pw_w"].t()))
+        return y.view(B, H, W, -1).permute(0, 3, 1, 2)
 
     def forward(self, x):
         if _pointwise_ok(self, x):
@@ -580,22 +583,15 @@ class _FpnBottleneck(torch.autograd.Function):
             cache.update(fpn_key=key, fpn_fwd=N.wino_filter(w_hi, m, False), fpn_bwd=N.wino_filter(w_hi, m, True),
                          fpn_lo=[weight[:, offs[i]:offs[i] + chans[i]].permute(2, 3, 0, 1).reshape(9 * Cout, chans[i])
                                  .contiguous() for i in lo])  # rows (tap, cout): F.linear -> (B,h,w,9*Cout)
-        buf = torch.empty(B, sum(chans[i] for i in hi), H, W, dtype=torch.float32, device=fs[0].device,
-                          memory_format=_CL)
-        off = 0
-        for i in hi:
-            sl = buf[:, off:off + chans[i]]
-            if tuple(fs[i].shape[2:]) == (H, W):
-                sl.copy_(fs[i])
-            else:
-                N.upsample_bilinear_cl(_dense_cl(fs[i]), (H, W), out=sl)
-            off += chans[i]
+        # the fine inputs are transformed side by side into the Winograd domain: no concatenation buffer
+        xs = [_dense_cl(fs[i]) if tuple(fs[i].shape[2:]) == (H, W) else N.upsample_bilinear_cl(_dense_cl(fs[i]), (H, W))
+              for i in hi]
         extra = None
         for j, i in enumerate(lo):
             f = _dense_cl(fs[i])
             G = F.linear(f.permute(0, 2, 3, 1), cache["fpn_lo"][j]).view(B, f.shape[2], f.shape[3], 9, Cout)
             extra = N.tap_gather(G, (H, W), extra)
-        y = N.wino_conv3x3_cl(buf, cache["fpn_fwd"], m, bias=shift, scale=scale, relu=True, addend=extra)
+        y = N.wino_conv3x3_cl(xs, cache["fpn_fwd"], m, bias=shift, scale=scale, relu=True, addend=extra)
         ctx.save_for_backward(y, scale)
         ctx.cache, ctx.m, ctx.hi, ctx.lo, ctx.chans = cache, m, hi, lo, chans
         ctx.shapes = [tuple(f.shape) for f in fs]

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: memory layouts inside the UperNet head, A/B of the NHWC up-sampling kernels, and the ATen ops
 (with input shapes) that account for the non-convolution time of one forward + input-gradient backward."""
+import math
 import os
 import sys
 import time
@@ -86,14 +87,15 @@ def main():
             step(model, x)
         torch.cuda.synchronize()
     seen = {}
-    for e in prof.events():  # who issues the big layout / slice copies?
-        if e.name in ("aten::copy_", "aten::contiguous", "aten::clone") and e.input_shapes and e.input_shapes[0] \
-                and len(e.input_shapes[0]) == 4 and e.input_shapes[0][1] >= 256 and e.input_shapes[0][2] >= 64:
+    for e in prof.events():  # who issues the big layout / slice copies and the device-to-device memcpys?
+        big = (e.name in ("aten::copy_", "aten::contiguous", "aten::clone") and e.input_shapes and e.input_shapes[0]
+               and len(e.input_shapes[0]) >= 2 and math.prod(e.input_shapes[0]) >= (1 << 22))
+        if big or ("emcpy" in e.name and e.cpu_parent is not None):
             chain, q = [], e.cpu_parent
             while q is not None and len(chain) < 5:
-                chain.append(q.name)
+                chain.append(q.name + (str(q.input_shapes[0]) if q.input_shapes else ""))
                 q = q.cpu_parent
-            k = (e.name, str(e.input_shapes[0]), " <- ".join(chain))
+            k = (e.name, str(e.input_shapes[0]) if e.input_shapes else "", " <- ".join(chain))
             seen[k] = seen.get(k, 0) + 1
     for k, v in seen.items():
         print(f"{v:3d}x {k[0]} {k[1]} <- {k[2]}")

@@ -227,9 +227,9 @@ def main():
             st = torch.cuda.current_stream().cuda_stream
             t = timeit({
                 f"M4 winograd F({m}x{m}) input transform {Cin}ch 128x128": lambda: L.sea_wino_input_transform(
-                    xw.data_ptr(), Cin, None, None, V.data_ptr(), B, Cin, 128, 128, m, st),
+                    xw.data_ptr(), Cin, None, None, V.data_ptr(), Cin, B, Cin, 128, 128, m, st),
                 f"M4 winograd F({m}x{m}) output transform {Cout}ch 128x128": lambda: L.sea_wino_output_transform(
-                    Mx.data_ptr(), None, None, 0, yw.data_ptr(), B, Cout, 128, 128, m, st),
+                    Mx.data_ptr(), None, None, None, 0, yw.data_ptr(), B, Cout, 128, 128, m, st),
             }, rounds=7)
             report(f"M4 winograd F({m}x{m}) input transform {Cin}ch 128x128", t[f"M4 winograd F({m}x{m}) input transform {Cin}ch 128x128"],
                    4 * (xw.numel() + V.numel()))

@@ -111,3 +111,54 @@ def test_api_surface_matches_reference_signatures():
     assert L.get_loss("CrossEntropy", -1, None).criterion.ignore_index == -1
     assert len(U.ADE_WTS) == 151 and len(U.VOC_WTS) == 21
     assert U.getModelName("UperNetForSemanticSegmentation", "ConvNeXt-T_CVST") == "UperNet_ConvNeXt-T_CVST"
+
+
+# ---------------------------------------------------------------------------- model-side host logic (no GPU needed)
+def test_cl_pixel_stride_recognises_nhwc_tensors_and_channel_slices(native):
+    cl = torch.channels_last
+    wide = torch.zeros(2, 24, 5, 7).contiguous(memory_format=cl)
+    assert native.cl_pixel_stride(wide) == 24
+    assert native.cl_pixel_stride(wide[:, 4:12]) == 24          # channel slice: pixel stride of the parent
+    assert native.cl_pixel_stride(wide[:, 4:10]) is None         # 6 channels: not a multiple of 4
+    assert native.cl_pixel_stride(wide[:, 2:10]) is None         # 8-byte aligned only
+    assert native.cl_pixel_stride(torch.zeros(2, 24, 5, 7)) is None          # NCHW
+    assert native.cl_pixel_stride(wide[:, :, 1:]) is None                     # not dense over pixels
+    assert native.cl_pixel_stride(torch.zeros(3, 8, 1, 1)) == 8              # 1x1 maps are NHWC and NCHW at once
+    assert native.cl_pixel_stride(wide.double()) is None
+    assert native._is_cl(wide) and not native._is_cl(torch.zeros(3, 8, 1, 1)) and not native._is_cl(wide[:, 4:12])
+
+
+def test_folded_batchnorm_and_frozen_parameter_scope():
+    from semseg.attacker import _FrozenParameters
+    from semseg.models import convnext_upernet as M
+    torch.manual_seed(0)
+    mod = M.ConvModule(8, 12, 1).eval()
+    mod.batch_norm.running_mean.normal_()
+    mod.batch_norm.running_var.uniform_(0.5, 2.0)
+    with torch.no_grad():
+        mod.batch_norm.weight.uniform_(0.5, 1.5)
+        mod.batch_norm.bias.normal_()
+    cache = {}
+    scale, shift = M._folded_bn(mod.batch_norm, None, cache)
+    z = torch.randn(3, 12, 4, 5)
+    torch.testing.assert_close(z * scale[None, :, None, None] + shift[None, :, None, None], mod.batch_norm(z),
+                               rtol=1e-5, atol=1e-6)
+    assert M._folded_bn(mod.batch_norm, None, cache)[0] is scale           # cached
+    mod.batch_norm.running_var.mul_(2.0)                                    # in-place update -> new fold
+    assert M._folded_bn(mod.batch_norm, None, cache)[0] is not scale
+    # fast paths are for HIP tensors with frozen parameters only: CPU tensors take the reference composition
+    x = torch.randn(2, 8, 6, 6)
+    assert not M._pointwise_ok(mod, x) and not M._wino_ok(mod.conv, x)
+    ref = torch.relu(mod.batch_norm(mod.conv(x)))
+    torch.testing.assert_close(mod(x), ref)
+    # the attack's parameter scope restores every flag, also when the forward raises
+    flags = [p.requires_grad for p in mod.parameters()]
+    mod.conv.weight.requires_grad_(False)
+    flags[0] = False
+    with _FrozenParameters(mod):
+        assert not any(p.requires_grad for p in mod.parameters())
+    assert [p.requires_grad for p in mod.parameters()] == flags
+    with pytest.raises(RuntimeError):
+        with _FrozenParameters(mod):
+            raise RuntimeError("forward failed")
+    assert [p.requires_grad for p in mod.parameters()] == flags

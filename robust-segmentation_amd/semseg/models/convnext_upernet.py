@@ -251,9 +251,20 @@ class Block(nn.Module):
             # channels_last trunk (what MIOpen's NHWC convolutions hand us): the whole block stays in NHWC
             xn = x.permute(0, 2, 3, 1)  # contiguous (B,H,W,C) view
             y = _DwConv7x7NHWC.apply(xn, self.dwconv.weight, self.dwconv.bias, _taps_major(self.dwconv))
-            y = self.pwconv2(self.act(self.pwconv1(self.norm(y))))
-            if self.gamma is not None:
-                y = self.gamma * y
+            y = self.act(self.pwconv1(self.norm(y)))
+            w2, b2, g = self.pwconv2.weight, self.pwconv2.bias, self.gamma
+            if g is not None and not (w2.requires_grad or g.requires_grad or (b2 is not None and b2.requires_grad)):
+                # frozen weights: the layer scale is folded into the second projection (one kernel less each way)
+                key = tuple((t.data_ptr(), t._version) for t in (w2, b2, g) if t is not None)
+                cache = self.__dict__.setdefault("_fold_cache", {})
+                if cache.get("key") != key:
+                    with torch.no_grad():
+                        cache.update(key=key, w=(w2 * g[:, None]).contiguous(), b=None if b2 is None else b2 * g)
+                y = F.linear(y, cache["w"], cache["b"])
+            else:
+                y = self.pwconv2(y)
+                if g is not None:
+                    y = g * y
             return (xn + y).permute(0, 3, 1, 2)
         y = depthwise7x7(self.dwconv, x)
         if no_drop and _fast_layout_ok(x) and y.is_contiguous():

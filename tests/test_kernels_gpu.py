@@ -817,3 +817,36 @@ def test_convnext_block_channels_last_path(N):
     assert outs[0][0].is_contiguous(memory_format=torch.channels_last)
     for a, b in zip(*outs):
         torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-4 * b.abs().max().item())
+
+
+def test_convnext_block_frozen_weights_fold_layer_scale(N):
+    """attack-time block (frozen parameters): NHWC path with M1 + M5 and the layer scale folded into pwconv2
+    against the plain PyTorch block; an in-place change of gamma invalidates the fold."""
+    from semseg.models import convnext_upernet as M
+    torch.manual_seed(2)
+    blk = M.Block(96).cuda().eval()
+    with torch.no_grad():
+        blk.gamma.mul_(torch.rand(96, device="cuda") + 0.5)
+        blk.pwconv2.bias.normal_()
+    for p in blk.parameters():
+        p.requires_grad_(False)
+    x = torch.randn(2, 96, 20, 28, device="cuda").contiguous(memory_format=torch.channels_last)
+
+    def run(flag):
+        M.USE_HIP_DWCONV = flag
+        try:
+            xi = x.clone(memory_format=torch.preserve_format).requires_grad_(True)
+            y = blk(xi)
+            (g,) = torch.autograd.grad(y.square().sum(), xi)
+            return y.detach(), g
+        finally:
+            M.USE_HIP_DWCONV = True
+
+    fast, ref = run(True), run(False)
+    assert "_fold_cache" in blk.__dict__
+    for a, b in zip(fast, ref):
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-4 * b.abs().max().item())
+    blk.gamma.mul_(3.0)
+    fast2, ref2 = run(True), run(False)
+    torch.testing.assert_close(fast2[0], ref2[0], rtol=2e-4, atol=2e-4 * ref2[0].abs().max().item())
+    assert not torch.allclose(fast2[0], fast[0])

@@ -314,8 +314,276 @@ def config1():
     npz("g8_config1_upernet_t", **out)
 
 
+# =====================================================================================================
+# Round-2 fixtures: real-model goldens for BASELINE configs[2..4] and the remaining API surface
+# =====================================================================================================
+def _purge_semseg():
+    for k in [k for k in sys.modules if k in ("semseg", "tools") or k.startswith(("semseg.", "tools."))]:
+        del sys.modules[k]
+
+
+def _build_state_dict(kind, backbone, n_cls):
+    """Seeded state-dict of the BUILD's model (the reference models load it strict=True: same schema)."""
+    pkg = os.path.join(ROOT, "robust-segmentation_amd")
+    sys.path.insert(0, pkg)
+    cwd = os.getcwd()
+    os.chdir(pkg)
+    try:
+        torch.manual_seed(0)
+        if kind == "upernet":
+            from semseg.models.convnext_upernet import UperNetForSemanticSegmentation as Mine
+            sd = Mine(backbone, n_cls, None).state_dict()
+        else:
+            from semseg.models import create_segmenter
+            from semseg.utils.utils import load_config_segmenter
+            cfg, _ = load_config_segmenter(backbone, n_cls)
+            sd = create_segmenter(cfg, None, backbone).state_dict()
+    finally:
+        os.chdir(cwd)
+        sys.path.remove(pkg)
+        _purge_semseg()
+    return sd
+
+
+def _reference_model(kind, backbone, n_cls, sd):
+    os.chdir(REF)
+    if kind == "upernet":
+        from semseg.models.uperforseg import UperNetForSemanticSegmentation as Ref
+        ref = Ref(backbone, n_cls, None)
+    else:
+        # create_segmenter always torch.load()s a checkpoint (segmenter.py:299): assemble the same modules directly
+        from semseg.models.segmenter import MaskTransformer, SegMenter, VisionTransformer, create_decoder  # noqa: F401
+        from semseg.utils.utils import load_config_segmenter
+        cfg, _ = load_config_segmenter(backbone, n_cls)
+        mc = dict(cfg)
+        dec = dict(mc.pop("decoder"))
+        dec["n_cls"] = mc["n_cls"]
+        mc.pop("backbone")
+        mc.pop("normalization")
+        mc["n_cls"] = 1000
+        mc["d_ff"] = 4 * mc["d_model"]
+        enc = VisionTransformer(**mc)
+        ref = SegMenter(enc, create_decoder(enc, dec, backbone=backbone), n_cls=n_cls, backbone=backbone)
+    ref.load_state_dict(sd, strict=True)
+    return ref.eval()
+
+
+def _real_model_golden(name, kind, backbone, n_cls, losses, pgd_steps=0):
+    """Sampled logits, step-0 / step-1 loss + accuracy + input-gradient pins and a 5-step apgd_largereps run of the
+    REAL reference on a full-size model with the build's seeded weights, 2 synthetic 512x512 images."""
+    import contextlib
+    import io
+    import time
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    sd = _build_state_dict(kind, backbone, n_cls)
+    ref = _reference_model(kind, backbone, n_cls, sd)
+    import semseg.attacker as A
+    import semseg.val as V
+    from semseg.utils.utils import ADE_WTS, VOC_WTS
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    w = torch.tensor(VOC_WTS if n_cls == 21 else ADE_WTS)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.rand(2, 3, 512, 512, generator=g)
+    with torch.no_grad():
+        logits0 = ref(x)
+    y = logits0.max(1)[1]
+    eps = 4.0 / 255
+    out = dict(y=y.to(torch.uint8 if n_cls <= 255 else torch.int16), eps=np.float64(eps))
+    sidx = torch.randperm(logits0.numel(), generator=torch.Generator().manual_seed(6))[:4096]
+    out.update(logit_idx=sidx, logit_samples=logits0.flatten()[sidx], logit_absmax=logits0.abs().max())
+
+    # ---- step pins at two fixed points: the clean image and a fixed perturbation of it
+    u = torch.rand(x.shape, generator=torch.Generator().manual_seed(77))
+    x1 = (x + 2 * eps * (2 * u - 1)).clamp(0.0, 1.0)          # the random start of stage 1 (radius 2 eps)
+    gidx = torch.randperm(x.numel(), generator=torch.Generator().manual_seed(8))[:8192]
+    out["grad_idx"] = gidx
+    mask_bg = (y != -1).float()
+    for tag, xp in (("p0", x), ("p1", x1)):
+        for loss in losses:
+            xin = xp.clone().requires_grad_(True)
+            lg = ref(xin)
+            lp = A.criterion_dict[loss](lg, y, w)
+            li = A.pixel_to_img_loss(lp, mask_bg)
+            (gr,) = torch.autograd.grad(li.sum(), [xin])
+            key = f"{tag}_{loss.replace('-', '_')}"
+            out[key + "_img"] = li.detach()
+            out[key + "_grad"] = gr.flatten()[gidx]
+            out[key + "_gradmax"] = gr.abs().max()
+        with torch.no_grad():
+            lg = ref(xp)
+        ce = A.pixel_to_img_loss(A.criterion_dict["ce-avg"](lg, y), mask_bg)
+        out[f"{tag}_ce_img"] = ce
+        out[f"{tag}_n_correct"] = (lg.max(1)[1] == y).view(2, -1).sum(-1)
+
+    # ---- the attack itself, 5 iterations, seeded random start (config-#1 style)
+    for loss in losses:
+        torch.manual_seed(4321)
+        t0 = time.time()
+        with contextlib.redirect_stdout(io.StringIO()):
+            xa, _, acc = A.apgd_largereps(ref, x.clone(), y, w, norm="Linf", eps=eps, n_iter=5, n_restarts=1,
+                                          use_rs=True, loss=loss, verbose=False, track_loss="ce-avg", log_path=None,
+                                          num_classes=n_cls, early_stop=True)
+        dt = time.time() - t0
+        with torch.no_grad():
+            pa = ref(xa).max(1)[1]
+        m_acc, a_acc, m_iou = A.compute_iou_acc(pa.clone(), y, n_cls)
+        idx = torch.randperm(xa.numel(), generator=torch.Generator().manual_seed(5))[:4096]
+        key = loss.replace("-", "_")
+        out.update({f"{key}_acc": acc, "idx": idx, f"{key}_x_adv_samples": xa.flatten()[idx], f"{key}_adv_aacc": a_acc,
+                    f"{key}_adv_miou": m_iou, f"{key}_adv_macc": m_acc, f"{key}_seconds": np.float64(dt),
+                    f"{key}_linf": (xa - x).abs().max()})
+        print(name, loss, "acc", acc.tolist(), "aAcc", float(a_acc), "mIoU", float(m_iou), f"{dt:.1f}s", flush=True)
+
+    # ---- PIR-AT inner PGD (configs[3]): Pgd_Attack_1, CE, 5 steps, alpha 1e-2, seeded uniform start
+    if pgd_steps:
+        torch.manual_seed(99)
+        xa, lg, _ = V.Pgd_Attack_1(epsilon=eps, alpha=1e-2, num_iter=pgd_steps, los="pgd").adv_attack(ref, x, y)
+        idx = torch.randperm(xa.numel(), generator=torch.Generator().manual_seed(5))[:4096]
+        lidx = torch.randperm(lg.numel(), generator=torch.Generator().manual_seed(6))[:4096]
+        with torch.no_grad():
+            ce_adv = torch.nn.functional.cross_entropy(ref(xa), y)
+            ce_clean = torch.nn.functional.cross_entropy(logits0, y)
+        out.update(pgd_seed=np.int64(99), pgd_steps=np.int64(pgd_steps), pgd_x_adv_samples=xa.flatten()[idx],
+                   pgd_logit_samples=lg.detach().flatten()[lidx], pgd_ce_adv=ce_adv, pgd_ce_clean=ce_clean,
+                   pgd_linf=(xa - x).abs().max())
+        print(name, "pgd ce clean/adv", float(ce_clean), float(ce_adv), flush=True)
+    npz(name, **out)
+
+
+def config3():
+    """BASELINE configs[2]: Segmenter ViT-S/16, ADE20K-shaped (C=151)."""
+    _real_model_golden("g9_config3_segmenter_vits", "segmenter", "vit_small_patch16_224", 151,
+                       ("mask-ce-bal", "mask-ce-avg", "js-avg"))
+
+
+def config4():
+    """BASELINE configs[3] and [4]: UperNet-ConvNeXt-S, ADE20K-shaped (C=151): SEA losses + the PIR-AT inner PGD."""
+    _real_model_golden("g10_config4_upernet_s", "upernet", "ConvNeXt-S_CVST", 151,
+                       ("mask-ce-bal", "mask-ce-avg", "js-avg"), pgd_steps=5)
+
+
+def config1_pins():
+    """Step-0 / step-1 pins for BASELINE configs[0]/[1] (UperNet-ConvNeXt-T, C=21), all three SEA losses."""
+    _real_model_golden("g11_config1_pins_upernet_t", "upernet", "ConvNeXt-T_CVST", 21,
+                       ("mask-ce-bal", "mask-ce-avg", "js-avg"))
+
+
+def extras():
+    """API-surface goldens: val.losses callables, general js_div_fn arguments, apgd_restarts, eval_performance."""
+    import contextlib
+    import io
+    os.makedirs(OUT, exist_ok=True)
+    os.chdir(REF)
+    torch.set_num_threads(4)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    import semseg.attacker as A
+    import semseg.val as V
+
+    from oracle.tiny_models import TinyConvNet, make_labels
+
+    # ---- val.losses (val.py:121-127) incl. gradients
+    g = torch.Generator().manual_seed(31)
+    C = 21
+    logits = torch.randn(2, C, 12, 10, generator=g) * 3
+    y = torch.randint(0, C, (2, 12, 10), generator=g)
+    boost = torch.rand(2, 12, 10, generator=g) < 0.6
+    logits.scatter_add_(1, y.unsqueeze(1), (boost.float() * 6).unsqueeze(1))
+    out = dict(logits=logits, y=y)
+    for name in ("pgd", "mask-ce-avg", "js-avg"):
+        z = logits.clone().requires_grad_(True)
+        l = V.losses[name](z, y)
+        (gr,) = torch.autograd.grad(l.sum(), [z])
+        out[name.replace("-", "_")] = l.detach()
+        out[name.replace("-", "_") + "_grad"] = gr
+    other = torch.randn(2, C, 12, 10, generator=g)
+    z = logits.clone().requires_grad_(True)
+    l = V.losses["l2-loss"](z, other)
+    (gr,) = torch.autograd.grad(l.sum(), [z])
+    out.update(l2_other=other, l2_loss=l.detach(), l2_loss_grad=gr)
+    npz("g12_val_losses", **out)
+
+    # ---- js_div_fn beyond the js_loss configuration (attacker.py:187-226)
+    g = torch.Generator().manual_seed(32)
+    C = 5
+    logits = torch.randn(2, C, 6, 7, generator=g) * 2
+    y = torch.randint(0, C, (2, 6, 7), generator=g)
+    y[torch.rand(2, 6, 7, generator=g) < 0.1] = -1
+    out = dict(logits=logits, y=y)
+    out["full"] = A.js_div_fn(logits, y)                                           # (B,C,H,W), no class sum
+    out["sum_c"] = A.js_div_fn(logits, y, red_dim=(1))
+    out["sum_chw"] = A.js_div_fn(logits, y, red_dim=(1, 2, 3))
+    out["from_probs"] = A.js_div_fn(torch.softmax(logits, 1), y, softmax_output=True, red_dim=(1))
+    z = logits.clone().requires_grad_(True)
+    (out["full_grad"],) = torch.autograd.grad(A.js_div_fn(z, y).sum(), [z])
+    y_all_ign = torch.full_like(y, -1)
+    out["allign_sum"] = A.js_div_fn(logits, y_all_ign, reduction="sum")            # the only legal non-"none" call
+    npz("g12_js_div_general", **out)
+
+    # ---- apgd_restarts (attacker.py:574-659): 2 restarts, random starts recorded
+    net = TinyConvNet(5, seed=12, gain=3.0)
+    g = torch.Generator().manual_seed(3100)
+    x = torch.rand(4, 3, 12, 12, generator=g)
+    y = make_labels(net, x, ignore_frac=0.04, flip_frac=0.05, seed=6)
+    with torch.no_grad():
+        y[0] = (net(x[:1]).max(1)[1][0] + 1) % 5   # image 0 is wrong everywhere: it drops out after restart 1
+    noises = []
+    real_rand_like = torch.rand_like
+
+    def rec_rand_like(t, *a, **k):
+        r = real_rand_like(t, *a, **k)
+        noises.append(r.clone())
+        return r
+
+    torch.rand_like = rec_rand_like
+    try:
+        torch.manual_seed(555)
+        with contextlib.redirect_stdout(io.StringIO()):
+            xa, acc_last, acc = A.apgd_restarts(net, x, y, norm="Linf", eps=0.12, n_iter=12, loss="mask-ce-avg",
+                                                n_restarts=3, early_stop=True, track_loss="ce-avg", use_rs=True)
+    finally:
+        torch.rand_like = real_rand_like
+    d = dict(x=x, y=y, eps=np.float64(0.12), n_iter=np.int64(12), n_restarts=np.int64(3), x_adv=xa, acc=acc,
+             acc_last=acc_last, n_noise=np.int64(len(noises)))
+    for i, nz in enumerate(noises):
+        d[f"noise_{i}"] = nz
+    print("restarts: acc", acc.tolist(), "noise shapes", [tuple(n.shape) for n in noises])
+    npz("g12_apgd_restarts", **d)
+
+    # ---- eval_performance (tools/infer.py:56-133).  tools/infer.py as a whole does not parse on Python 3.10
+    # (f-string quoting at its last lines), so the function is executed from the file's own text in memory.
+    src = open(os.path.join(REF, "tools", "infer.py")).read()
+    start = src.index("def eval_performance(")
+    end = src.index("def evaluate(", start)
+    ns = {"torch": torch}
+    exec(compile(src[start:end], "tools/infer.py[eval_performance]", "exec"), ns)
+    real_to = torch.Tensor.to
+    torch.Tensor.to = lambda self, *a, **k: self if (a and a[0] == "cuda") else real_to(self, *a, **k)
+    try:
+        for tag, (C, n_b, nb_arg) in {"a": (5, 3, -1), "b": (21, 4, 3)}.items():
+            net = TinyConvNet(C, seed=20 + C)
+            g = torch.Generator().manual_seed(3200 + C)
+            loader = []
+            for b in range(n_b):
+                xb = torch.rand(2 if b < n_b - 1 else 1, 3, 16, 16, generator=g)
+                yb = make_labels(net, xb, ignore_frac=0.06, flip_frac=0.3, seed=b)
+                loader.append((xb, yb, "n"))
+            with contextlib.redirect_stdout(io.StringIO()):
+                stats, l_out = ns["eval_performance"](net, loader, n_batches=nb_arg, n_cls=C, ignore_index=-1)
+            npz(f"g12_eval_performance_{tag}", n_cls=np.int64(C), n_batches=np.int64(nb_arg), seed_net=np.int64(20 + C),
+                images=torch.cat([b[0] for b in loader]), targets=torch.cat([b[1] for b in loader]),
+                sizes=np.array([b[0].shape[0] for b in loader]), mAcc=np.float64(stats["mAcc"]),
+                aAcc=np.float64(stats["aAcc"]), mIoU=np.float64(stats["mIoU"]), l_output=l_out)
+    finally:
+        torch.Tensor.to = real_to
+
+
 if __name__ == "__main__":
-    if "--config1" in sys.argv:
-        config1()
+    flags = {"--config1": config1, "--config1-pins": config1_pins, "--config3": config3, "--config4": config4,
+             "--extras": extras}
+    chosen = [f for a, f in flags.items() if a in sys.argv]
+    if chosen:
+        for f in chosen:   # one flag per process is the tested way (each imports the reference afresh)
+            f()
     else:
         main()

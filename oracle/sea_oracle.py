@@ -400,6 +400,32 @@ def apgd_train(model, x, y, norm="Linf", eps=8.0 / 255, n_iter=10, use_rs=False,
     return x_best, acc, loss_best, x_best_adv
 
 
+def apgd_restarts(model, x, y, eps=8.0 / 255, n_iter=10, loss="mask-ce-avg", n_restarts=1, early_stop=False,
+                  track_loss=None, use_rs=False, noises=None):
+    """APGD with restarts on the images whose pixel accuracy is still > 0 (semseg/attacker.py:574-659).
+    ``noises[r]`` replaces the random start of restart r (it has the shape of the active sub-batch).
+    Returns (x_adv, acc of the last apgd_train call, acc)."""
+    B = x.shape[0]
+    acc = torch.ones(B)
+    x_adv = x.clone()
+    acc_last = None
+    for r in range(n_restarts):
+        ind = acc > 0
+        if acc.sum() > 0:
+            _, acc_last, _, cand = apgd_train(model, x[ind], y[ind], eps=eps, n_iter=n_iter, use_rs=use_rs, loss=loss,
+                                              early_stop=early_stop, track_loss=track_loss,
+                                              noise=None if noises is None else noises[r])
+            with torch.no_grad():
+                ok = model(cand).max(1)[1] == y[ind]
+            ok[y[ind] == -1] = True
+            acc_c = ok.float().reshape(cand.shape[0], -1).mean(-1)
+            upd = acc_c < acc[ind]
+            rows = torch.nonzero(ind).flatten()[upd]
+            x_adv[rows] = cand[upd]
+            acc[rows] = acc_c[upd]
+    return x_adv, acc_last, acc
+
+
 def largereps_schedule(n_iter: int, eps: float):
     """Stage lengths and radii of the 3-stage schedule (semseg/attacker.py:693-695)."""
     n_iters = [int(c * n_iter) for c in (0.3, 0.3)]
@@ -429,6 +455,8 @@ def apgd_largereps(model, x, y, weights, norm="Linf", eps=8.0 / 255, n_iter=10, 
 def _val_loss(logits, y, los: str):
     """The `losses` table of semseg/val.py:104-127 (no ignore handling there)."""
     B = logits.shape[0]
+    if los == "l2-loss":   # here `y` is a tensor of the logits' shape (semseg/val.py:125)
+        return ((logits - y) ** 2).reshape(B, -1).sum(-1)
     lse = torch.logsumexp(logits, 1)
     zy = logits.gather(1, y.unsqueeze(1)).squeeze(1)
     ce = lse - zy
@@ -443,6 +471,30 @@ def _val_loss(logits, y, los: str):
         js = LN2 + 0.5 * (py * logp - (1.0 + py) * torch.log1p(py))
         return js.reshape(B, -1).mean(-1)
     raise ValueError(los)
+
+
+def js_div_general(p, q, softmax_output=False, reduction="none", red_dim=None):
+    """js_div_fn for arbitrary arguments (semseg/attacker.py:187-226), written out element-wise:
+    0.5 * (KL(p || m) + KL(onehot || m)) per class with m = (p + onehot) / 2, the 0*log(0) = 0 convention of
+    F.kl_div for zero targets, ignored pixels zeroed, optional sum over ``red_dim``.  ``reduction="sum"`` is
+    only legal when every pixel is ignored (line 209); the result is then that scalar times the (all-zero)
+    mask, shape (B,1,H,W)."""
+    prob = p if softmax_output else torch.softmax(p, 1)
+    keep = q != -1
+    if reduction != "none" and keep.sum() > 0:
+        raise ValueError("Incompatible setup.")
+    ys = torch.where(keep, q, torch.zeros_like(q))
+    onehot = torch.zeros_like(prob).scatter_(1, ys.unsqueeze(1), 1.0)
+    log_m = torch.log((prob + onehot) / 2)
+    term = 0.5 * ((torch.xlogy(prob, prob) - prob * log_m) + (torch.xlogy(onehot, onehot) - onehot * log_m))
+    if reduction == "sum":
+        term = term.sum()
+    elif reduction == "mean":
+        term = term.mean()
+    out = keep.unsqueeze(1).to(prob.dtype) * term
+    if red_dim is not None:
+        out = out.sum(dim=red_dim)
+    return out
 
 
 def pgd_attack_1(model, X, y, epsilon=4.0 / 255, alpha=1e-2, num_iter=2, los="pgd", delta0=None):
@@ -491,6 +543,29 @@ def eval_stats_from_counts(inter, pred_cnt, tgt_cnt):
     ind = union > 0
     m_iou = (inter[ind] / union[ind]).mean()
     return {"mAcc": m_acc.item(), "aAcc": a_acc.item(), "mIoU": m_iou.item()}
+
+
+def eval_performance(model, loader, n_batches: int = -1, n_cls: int = 21):
+    """Clean / adversarial evaluation pass (tools/infer.py:56-133): ``loader`` yields (input, target, ...);
+    returns ({mAcc, aAcc, mIoU}, concatenated argmax maps (N,H,W) int64).  The returned maps carry the ignore
+    label at ignored pixels because the reference overwrites ``pred`` in place after appending it (lines 88-90)."""
+    inter = torch.zeros(n_cls, dtype=torch.int64)
+    pc = torch.zeros(n_cls, dtype=torch.int64)
+    tc = torch.zeros(n_cls, dtype=torch.int64)
+    outs = []
+    for i, vals in enumerate(loader):
+        inp, target = vals[0], vals[1]
+        with torch.no_grad():
+            pred = model(inp).max(1)[1]
+        pred[target == -1] = -1
+        outs.append(pred)
+        a, b, c = class_counts(pred, target, n_cls, per_image=False, mask_pred=False)
+        inter += a
+        pc += b
+        tc += c
+        if i + 1 == n_batches:
+            break
+    return eval_stats_from_counts(inter, pc, tc), torch.cat(outs)
 
 
 def worst_case_acc(preds: torch.Tensor, targets: torch.Tensor, n_cls: int, bs: Optional[int] = None):

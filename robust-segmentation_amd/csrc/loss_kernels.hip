@@ -231,6 +231,14 @@ __global__ __launch_bounds__(256, (TUNE & 4) ? 4 : 1) void loss_nchw_reg(const T
       z[c][v] = e;
       s += e;
     }
+    // torch.max semantics for non-finite logits (reference attacker.py:145, 370, 485): the first NaN wins, else the
+    // first maximum.  The fmaxf chain above ignores NaNs, but then exp(z - m) is NaN exactly at the NaN logits (and
+    // at the +inf logits when the maximum is +inf, and everywhere when all logits are -inf), so the sum flags the
+    // case and the first NaN among the e's is torch's index in all of them.  Never taken for finite logits.
+    if (__builtin_expect(s != s, 0)) {
+#pragma unroll
+      for (int c = CPAD - 1; c >= 0; --c) arg = (z[c][v] != z[c][v]) ? c : arg;
+    }
     const bool valid = active && lab[v] >= 0;
     const bool correct = valid && (arg == lab[v]);
     const float lse = m + __logf(s);
@@ -324,7 +332,7 @@ __global__ __launch_bounds__(256) void loss_nchw_stream(const T* __restrict__ lo
     for (int c = 1; c < C; ++c) {
       const float zc = Elem<T>::to_f(lbase[(int64_t)c * HW]);
       zy = (lab == c) ? zc : zy;
-      if (zc > m) {
+      if (!(zc <= m) && !(m != m)) {  // zc > m, or zc is the first NaN (torch.max: a NaN wins and stays)
         s = s * __expf(m - zc) + 1.f;
         m = zc;
         arg = c;
@@ -393,7 +401,7 @@ __global__ __launch_bounds__(256) void loss_nhwc_lds(const T* __restrict__ logit
     int arg = 0;
     for (int c = 1; c < C; ++c) {
       const float zc = row[c];
-      if (zc > m) {
+      if (!(zc <= m) && !(m != m)) {  // zc > m, or zc is the first NaN (torch.max semantics)
         m = zc;
         arg = c;
       }

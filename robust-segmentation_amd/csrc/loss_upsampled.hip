@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void loss_upsampled_kernel(
       const float z = lerp2(a0, same_col ? a0 : a1, b0, same_col ? b0 : b1, lx, ly);
       zy = (lab == c) ? z : zy;
       const float e = __expf(-fabsf(z - m));  // exp(-inf) = 0 on the first class
-      if (z > m) {                              // strict: first maximum wins
+      if (!(z <= m) && !(m != m)) {             // z > m (strict: first maximum wins), or z is the first NaN (torch.max)
         s = s * e + 1.f;
         m = z;
         arg = c;

@@ -97,12 +97,33 @@ def masked_cross_entropy_balanced(pred, target, weights=None, reduction="none", 
     return loss
 
 
+def _is_class_dim(red_dim) -> bool:
+    return red_dim in (1, (1,), [1])
+
+
 def js_div_fn(p, q, weights=None, softmax_output=False, reduction="none", red_dim=None, ignore_index=-1):
-    """JS divergence between softmax(p) and one-hot(q) (reference lines 187-226).  The fused kernel
-    yields the class-summed value, so ``red_dim`` must sum over the class dim (what js_loss does)."""
-    if softmax_output or reduction != "none" or red_dim not in (1, (1,), [1]):
-        raise NotImplementedError("only the js_loss configuration (logits in, red_dim=1) is implemented in HIP")
-    return _loss_map(p, q, None, 2)
+    """JS divergence between softmax(p) and one-hot(q) (reference lines 187-226).
+
+    The configuration the attack uses (logits in, ``reduction="none"``, summed over the class dim: what
+    ``js_loss`` passes) runs in the fused kernel K2 in closed form (NaN-free).  Every other
+    argument combination is cold API surface and is composed from device tensor ops with the reference's
+    semantics, including its quirks: ``reduction != "none"`` raises unless every pixel is ignored (line 209),
+    ignored pixels contribute 0, and a soft-max that underflows to exactly 0 yields NaN like the reference."""
+    if not softmax_output and reduction == "none" and _is_class_dim(red_dim):
+        return _loss_map(p, q, None, 2)
+    prob = p if softmax_output else torch.softmax(p, 1)
+    keep = q != ignore_index
+    if reduction != "none" and bool(keep.any()):
+        raise ValueError("Incompatible setup.")
+    onehot = torch.zeros_like(prob).scatter_(1, torch.where(keep, q, torch.zeros_like(q)).unsqueeze(1), 1.0)
+    log_m = ((prob + onehot) / 2).log()
+    kl = torch.nn.functional.kl_div
+    loss = (kl(log_m, prob, reduction=reduction) + kl(log_m, onehot, reduction=reduction)) / 2
+    loss = keep.unsqueeze(1).to(loss.dtype) * loss
+    if red_dim is not None:
+        assert reduction == "none", "Incompatible setup."
+        loss = loss.sum(dim=red_dim)
+    return loss
 
 
 def js_loss(p, q, num_classes=21, reduction="mean"):
@@ -370,12 +391,14 @@ class ApgdRun:
 
 def apgd_train(model, x, y, norm, eps, n_iter=10, use_rs=False, loss="ce", verbose=False, is_train=False,
                early_stop=False, track_loss=None, logger=None, y_target=None, ignore_index=-1, x_init=None,
-               num_classes=21, weights=None, gpuu=None, noise=None, poll_every: int = 8):
+               num_classes=21, weights=None, gpuu=None, noise=None, poll_every: int = 8, return_pred: bool = False):
     """One APGD run (reference lines 260-571).  Returns ``(x_best, acc, loss_best, x_best_adv)``.
 
     Extra keyword arguments (all optional): ``gpuu`` is accepted and ignored (tools/train_rob_seg.py
     passes it); ``noise`` replaces ``torch.rand_like(x)`` of the random start so CPU and
-    device runs can share it; ``poll_every`` = how often the host looks at the early-stop flag.
+    device runs can share it; ``poll_every`` = how often the host looks at the early-stop flag;
+    ``return_pred`` appends the argmax map of ``x_best_adv`` (uint8 / int16, produced by the attack's own fused
+    kernel on the forward that evaluated that iterate) to the returned tuple.
     """
     assert not model.training
     assert ignore_index == -1, "Only `ignore_index = 1` is supported."
@@ -400,7 +423,8 @@ def apgd_train(model, x, y, norm, eps, n_iter=10, use_rs=False, loss="ce", verbo
 
     run = ApgdRun(model, x, y, eps, n_iter, loss, track_loss, early_stop, num_classes, weights, x_adv)
     run.defer = not verbose  # the verbose log line reads the per-image sums on the host
-    if logger is not None and verbose:
+    if logger is not None:
+        # reference lines 302-306 log this whenever ignore labels exist (one host read per run, outside the loop)
         n_ign = int(run.n_ignored.sum())
         if n_ign > 0:
             logger.log(f"{n_ign / y.numel():.2%} pixels are masked out.")
@@ -431,36 +455,48 @@ def apgd_train(model, x, y, norm, eps, n_iter=10, use_rs=False, loss="ce", verbo
                 done_host.copy_(run.st.done, non_blocking=True)
                 done_evt = torch.cuda.Event()
                 done_evt.record()
+    if return_pred:
+        return run.result() + (run.pred_best,)
     return run.result()
 
 
 def apgd_restarts(model, x, y, norm="Linf", eps=8.0 / 255.0, n_iter=10, loss="ce", verbose=False, n_restarts=1,
-                  log_path=None, early_stop=False, eot_iter=0, track_loss=None, use_rs=False, ignore_index=-1):
+                  log_path=None, early_stop=False, eot_iter=0, track_loss=None, use_rs=False, ignore_index=-1,
+                  noises=None):
     """APGD with restarts on the still-robust images (reference lines 574-659).  Not used by SEA
-    (tools/infer.py uses apgd_largereps); kept for API parity.  Targeted losses are not implemented."""
+    (tools/infer.py uses apgd_largereps); kept for API parity.  Targeted losses are not implemented.
+    Returns ``(x_adv, acc_of_last_run, acc)`` like the reference's ``(x_adv, _, acc)``.  ``noises[r]``
+    (optional) replaces the uniform draw of restart r's random start (shape of the active sub-batch).
+
+    The candidate's pixel accuracy (reference lines 631-634: a re-forward, ignored pixels counted as
+    correct) comes from one no-gradient K2 launch on the re-forwarded logits."""
     if "targeted" in loss:
         raise NotImplementedError("targeted losses are outside the SEA hot path")
     logger = Logger(log_path)
-    acc = torch.ones([x.shape[0]], device=x.device)
+    B, HW = x.shape[0], x.shape[-2] * x.shape[-1]
+    acc = torch.ones(B, device=x.device)
     x_adv = x.clone()
-    for i in range(n_restarts):
-        ind = acc > 0
-        if acc.sum() > 0:
-            _, _, _, x_adv_curr = apgd_train(model, x[ind], y[ind], n_iter=n_iter, use_rs=use_rs, verbose=verbose,
-                                             loss=loss, eps=eps, norm=norm, logger=logger, early_stop=early_stop,
-                                             track_loss=track_loss, ignore_index=ignore_index)
-            with torch.no_grad():
-                pred = model(x_adv_curr).max(1)[1] == y[ind]
-            pred[y[ind] == ignore_index] = True
-            acc_curr = pred.float().view(x_adv_curr.shape[0], -1).mean(-1)
-            to_update = acc_curr < acc[ind]
-            succs = torch.nonzero(ind).squeeze()
-            if len(succs.shape) == 0:
-                succs.unsqueeze_(0)
-            x_adv[succs[to_update]] = x_adv_curr[to_update].clone()
-            acc[succs[to_update]] = acc_curr[to_update].clone()
-            logger.log(f"restart {i + 1} robust accuracy={acc.float().mean():.1%}")
-    return x_adv, None, acc
+    acc_last_run = None
+    for r in range(n_restarts):
+        rows = torch.nonzero(acc > 0).flatten()            # images that are still robust
+        if rows.numel() == 0:
+            continue
+        xs, ys = x[rows], y[rows]
+        _, acc_last_run, _, cand = apgd_train(model, xs, ys, n_iter=n_iter, use_rs=use_rs, verbose=verbose, loss=loss,
+                                              eps=eps, norm=norm, logger=logger, early_stop=early_stop,
+                                              track_loss=track_loss, y_target=None, ignore_index=ignore_index,
+                                              noise=None if noises is None else noises[r])
+        _, logits = _forward_logits(model, cand, False)
+        yc = compact_labels(ys, logits.shape[1])
+        st = N.loss_fwd_bwd(logits, yc, None, 3, 3, 0.0, want_grad=False)
+        n_ign = N.count_ignored(yc)
+        acc_cand = (st["n_correct"] + n_ign).float() / float(HW)
+        better = acc_cand < acc[rows]
+        x_adv[rows[better]] = cand[better]
+        acc[rows[better]] = acc_cand[better]
+        note = " (warning: this is only upper bound on aAcc)" if bool((n_ign > 0).any()) else ""
+        logger.log(f"restart {r + 1} robust accuracy={acc.float().mean():.1%}{note}")
+    return x_adv, acc_last_run, acc
 
 
 def largereps_schedule(n_iter: int, eps: float):
@@ -472,9 +508,11 @@ def largereps_schedule(n_iter: int, eps: float):
 
 def apgd_largereps(model, x, y, weights, norm="Linf", eps=8.0 / 255.0, n_iter=10, loss="ce", verbose=False,
                    n_restarts=1, log_path=None, early_stop=False, eot_iter=0, track_loss=None, use_rs=False,
-                   ignore_index=-1, num_classes=21, noises=None):
+                   ignore_index=-1, num_classes=21, noises=None, return_pred: bool = False):
     """The SEA attack schedule: three APGD stages at radii 2eps, 1.5eps, eps (reference lines 662-728).
-    Returns ``(x_adv, None, acc)`` with x_adv the lowest-pixel-accuracy iterate of the last stage."""
+    Returns ``(x_adv, None, acc)`` with x_adv the lowest-pixel-accuracy iterate of the last stage; with
+    ``return_pred`` also the argmax map of x_adv (so callers such as tools/infer.py need not re-forward it,
+    reference tools/infer.py:136-155 + 356-364)."""
     if norm != "Linf":
         raise NotImplementedError()
     logger = Logger(log_path)
@@ -485,9 +523,11 @@ def apgd_largereps(model, x, y, weights, norm="Linf", eps=8.0 / 255.0, n_iter=10
     for s, (inner_it, inner_eps) in enumerate(zip(n_iters, epss)):
         if x_init is not None:
             x_init = N.linf_project(x_init.contiguous(), xc, float(inner_eps))  # reference lines 683-690
-        _, acc, _, x_init = apgd_train(model, xc, y, n_iter=inner_it, use_rs=use_rs, verbose=verbose, loss=loss,
-                                       eps=inner_eps, norm=norm, logger=logger, early_stop=early_stop,
-                                       track_loss=track_loss, y_target=None, ignore_index=ignore_index,
-                                       x_init=x_init, num_classes=num_classes, weights=weights,
-                                       noise=None if noises is None else noises[s])
+        _, acc, _, x_init, pred = apgd_train(model, xc, y, n_iter=inner_it, use_rs=use_rs, verbose=verbose, loss=loss,
+                                             eps=inner_eps, norm=norm, logger=logger, early_stop=early_stop,
+                                             track_loss=track_loss, y_target=None, ignore_index=ignore_index,
+                                             x_init=x_init, num_classes=num_classes, weights=weights,
+                                             noise=None if noises is None else noises[s], return_pred=True)
+    if return_pred:
+        return x_init, None, acc, pred
     return x_init, None, acc

@@ -11,25 +11,59 @@ from __future__ import annotations
 import torch
 
 from . import _native as N
+from . import attacker as _A
 from .attacker import _FrozenParameters
 from .metrics import Metrics
 
-__all__ = ["Pgd_Attack", "Pgd_Attack_1", "evaluate", "losses"]
+__all__ = ["Pgd_Attack", "Pgd_Attack_1", "evaluate", "losses", "js_loss", "masked_cross_entropy"]
 
-# name -> (K2 mode, per-image loss?)   (the `losses` table of val.py:121-127; none of them knows ignore labels)
-losses = {"pgd": (3, False), "mask-ce-avg": (0, True), "js-avg": (2, True)}
+
+def js_loss(p, q, reduction="mean"):
+    """val.py:103-108: JS divergence summed over classes, per-image mean by default."""
+    return _A.js_loss(p, q, reduction=reduction)
+
+
+def masked_cross_entropy(pred, target):
+    """val.py:111-117: per-image mean of the cross-entropy of the correctly classified pixels."""
+    return _A.masked_cross_entropy(pred, target, reduction="mean")
+
+
+class _ValLoss:
+    """One entry of the `losses` table (val.py:121-127): a differentiable callable ``fn(logits, y)`` like the
+    reference's, plus what the PGD classes below need to run it as ONE fused K2 launch instead of through
+    autograd: ``mode`` (K2 loss id, None = no fused form) and ``per_image`` (False: scalar mean over the batch)."""
+
+    def __init__(self, fn, mode, per_image):
+        self.fn, self.mode, self.per_image = fn, mode, per_image
+
+    def __call__(self, x, y):
+        return self.fn(x, y)
+
+
+# none of these knows ignore labels (F.cross_entropy's default ignore_index is -100 there)
+losses = {
+    "pgd": _ValLoss(lambda x, y: _A._ce(x, y).mean(), 3, False),
+    "mask-ce-avg": _ValLoss(masked_cross_entropy, 0, True),
+    "js-avg": _ValLoss(js_loss, 2, True),
+    "l2-loss": _ValLoss(lambda x, y: ((x - y) ** 2).view(x.shape[0], -1).sum(-1), None, True),
+}
 
 
 def _labels(y):
     return y.long().contiguous() if y.dtype not in (torch.int64, torch.int32, torch.int16, torch.uint8) else y.contiguous()
 
 
-def _fwd_grad(model, x_in, y, mode, scale, ws, out, dlogits):
-    """logits = model(x_in); returns (input gradient of sum of the loss, K2 stats, logits)."""
+def _fwd_grad(model, x_in, y, los, scale, ws, out, dlogits):
+    """logits = model(x_in); returns (input gradient of sum of the loss, K2 stats, logits).  Losses without a
+    fused form (``l2-loss``) go through autograd on the callable."""
     x_in = x_in.detach().requires_grad_(True)
     with torch.enable_grad(), _FrozenParameters(model):  # gradient w.r.t. the input only (val.py:150, 201)
         logits = model(x_in)
-    r = N.loss_fwd_bwd(logits.detach(), y, None, mode, mode, scale, want_grad=True, workspace=ws, out=out,
+        if los.mode is None:
+            li = los(logits, y)
+            (g,) = torch.autograd.grad(li.sum(), [x_in])
+            return g.contiguous(), dict(dlogits=None, loss_img=li.detach()), logits.detach()
+    r = N.loss_fwd_bwd(logits.detach(), y, None, los.mode, los.mode, scale, want_grad=True, workspace=ws, out=out,
                        dlogits=dlogits)
     (g,) = torch.autograd.grad(logits, [x_in], grad_outputs=r["dlogits"])
     return g.contiguous(), r, logits.detach()
@@ -40,13 +74,14 @@ class Pgd_Attack_1:
 
     def __init__(self, epsilon=4.0 / 255.0, alpha=1e-2, num_iter=2, los="pgd"):
         self.epsilon, self.alpha, self.num_iter, self.los_name = epsilon, alpha, num_iter, los
-        self.mode, self.per_image = losses[los]
+        self.loss_fn = losses[los]
+        self.mode, self.per_image = self.loss_fn.mode, self.loss_fn.per_image
 
     def adv_attack(self, model, X, y, delta0=None):
         model.eval()
         X = X.detach().contiguous().float()
         B, HW = X.shape[0], X.shape[-2] * X.shape[-1]
-        y = _labels(y)
+        y = _labels(y) if self.mode is not None else y
         delta = torch.zeros_like(X).uniform_(-self.epsilon, self.epsilon) if delta0 is None else delta0.clone()
         # F.cross_entropy(x, y) is the mean over all B*H*W pixels (val.py:122); the others are per-image means
         scale = 1.0 / (HW if self.per_image else B * HW)
@@ -55,7 +90,7 @@ class Pgd_Attack_1:
         x_in = X + delta
         logits, dl = None, None
         for _ in range(self.num_iter):
-            g, r, logits = _fwd_grad(model, x_in, y, self.mode, scale, ws, out, dl)
+            g, r, logits = _fwd_grad(model, x_in, y, self.loss_fn, scale, ws, out, dl)
             dl = r["dlogits"]
             N.pgd_linf_step(X, delta, g, float(self.alpha), float(self.epsilon), delta_out=delta, x_in_out=x_in,
                             clamp_input=False)
@@ -71,7 +106,8 @@ class Pgd_Attack:
     def __init__(self, eps=4.0 / 255.0, alpha=1e-2, num_iter=2, los="pgd", epsilon=None):
         self.epsilon = eps if epsilon is None else epsilon
         self.alpha, self.num_iter, self.los_name = alpha, num_iter, los
-        self.mode, self.per_image = losses[los]
+        self.loss_fn = losses[los]
+        self.mode, self.per_image = self.loss_fn.mode, self.loss_fn.per_image
         if not self.per_image:
             # the reference indexes a scalar loss per image here and raises IndexError
             raise ValueError("Pgd_Attack needs a per-image loss ('mask-ce-avg' or 'js-avg'); use Pgd_Attack_1 for 'pgd'")
@@ -80,7 +116,7 @@ class Pgd_Attack:
         model.eval()
         X = X.detach().contiguous().float()
         B, HW = X.shape[0], X.shape[-2] * X.shape[-1]
-        y = _labels(y)
+        y = _labels(y) if self.mode is not None else y
         delta = torch.zeros_like(X)
         best_delta = torch.zeros_like(X)
         best = torch.zeros(B, device=X.device)
@@ -89,9 +125,9 @@ class Pgd_Attack:
         x_in = X.clamp(0.0, 1.0)
         dl = None
         for _ in range(self.num_iter):
-            g, r, _ = _fwd_grad(model, x_in, y, self.mode, 1.0 / HW, ws, out, dl)
+            g, r, _ = _fwd_grad(model, x_in, y, self.loss_fn, 1.0 / HW, ws, out, dl)
             dl = r["dlogits"]
-            loss = r["loss_sum"] / HW
+            loss = r["loss_img"] if "loss_img" in r else r["loss_sum"] / HW
             ind = loss >= best
             best = torch.where(ind, loss, best)
             N.pgd_linf_step(X, delta, g, float(self.alpha), float(self.epsilon), delta_out=delta, x_in_out=x_in,

@@ -53,18 +53,18 @@ class SeaStats:
         self.clean[1] += pred_cnt
         self.clean[2] += tgt_cnt
 
-    def add_attack_batch(self, a: int, global_idx, inter_mask, pred_mask, tgt_cnt, inter_raw, pred_raw):
-        """Per-image (b,C) counts of one attacked batch.
-
-        *_mask: counts with predictions masked at ignored pixels (dataset totals, tools/infer.py:90-116);
-        *_raw : counts without that masking (per-image tables, tools/worse_only.py:49-66)."""
+    def add_attack_batch(self, a: int, global_idx, inter, pred_cnt, tgt_cnt):
+        """Per-image (b,C) counts of one attacked batch, predictions masked at ignored pixels: that is what
+        both consumers see in the reference, the dataset totals (tools/infer.py:88-116) and the per-image tables
+        of evalSEA, whose input logs were masked in place by eval_performance (infer.py:88-90; worse_only.py:49-66
+        itself does not mask)."""
         idx = torch.as_tensor(global_idx, device=self.buf.device)
-        self.attack_totals[a, 0] += inter_mask.sum(0)
-        self.attack_totals[a, 1] += pred_mask.sum(0)
+        self.attack_totals[a, 0] += inter.sum(0)
+        self.attack_totals[a, 1] += pred_cnt.sum(0)
         self.attack_totals[a, 2] += tgt_cnt.sum(0)
-        self.inter[a, idx] = inter_raw
-        self.union[a, idx] = tgt_cnt + pred_raw - inter_raw
-        self.correct[a, idx] = inter_raw.sum(-1)
+        self.inter[a, idx] = inter
+        self.union[a, idx] = tgt_cnt + pred_cnt - inter
+        self.correct[a, idx] = inter.sum(-1)
         self.valid[idx] = tgt_cnt.sum(-1)
 
     # ---- the one collective ----------------------------------------------------------------------

@@ -156,3 +156,66 @@ def test_g7_evalsea(tag):
     assert torch.equal(ints, g["ints"]) and torch.equal(unis, g["unions"])
     final, sel, rounds = O.worst_case_miou(ints, unis, rng=random.Random(225))
     assert final == g["final_miou"]  # exact: same float64 arithmetic, same shuffle stream
+
+
+# ---------------------------------------------------------------------------------------------------
+# round-2 fixtures: remaining API surface (oracle/gen_goldens.py --extras)
+# ---------------------------------------------------------------------------------------------------
+def test_g12_val_losses_table():
+    """semseg/val.py:121-127: pgd (scalar mean CE), mask-ce-avg / js-avg (per-image means), l2-loss."""
+    g = load_golden("g12_val_losses")
+    logits, y = g["logits"], g["y"]
+    for name, other in (("pgd", y), ("mask-ce-avg", y), ("js-avg", y), ("l2-loss", g["l2_other"])):
+        key = name.replace("-", "_")
+        z = logits.clone().requires_grad_(True)
+        val = O._val_loss(z, other, name)
+        torch.testing.assert_close(val.detach(), torch.as_tensor(g[key]), rtol=1e-5, atol=1e-6)
+        # the mask of mask-ce-avg is a constant of the autograd graph in the reference too (val.py:113)
+        (gr,) = torch.autograd.grad(val.sum(), [z])
+        torch.testing.assert_close(gr, g[key + "_grad"], rtol=1e-4, atol=2e-8)
+
+
+def test_g12_js_div_general_arguments():
+    g = load_golden("g12_js_div_general")
+    logits, y = g["logits"], g["y"]
+    torch.testing.assert_close(O.js_div_general(logits, y), g["full"], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(O.js_div_general(logits, y, red_dim=(1)), g["sum_c"], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(O.js_div_general(logits, y, red_dim=(1, 2, 3)), g["sum_chw"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(O.js_div_general(torch.softmax(logits, 1), y, softmax_output=True, red_dim=(1)),
+                               g["from_probs"], rtol=1e-5, atol=1e-7)
+    # the class-summed general form equals the closed form the fused kernel uses (SURVEY fact 4)
+    torch.testing.assert_close(O.pixel_losses(logits, y, None, O.MODE_JS), g["sum_c"], rtol=1e-4, atol=1e-6)
+    z = logits.clone().requires_grad_(True)
+    (gr,) = torch.autograd.grad(O.js_div_general(z, y).sum(), [z])
+    torch.testing.assert_close(gr, g["full_grad"], rtol=1e-4, atol=1e-7)
+    with pytest.raises(ValueError):
+        O.js_div_general(logits, y, reduction="sum")          # legal only when every pixel is ignored
+    out = O.js_div_general(logits, torch.full_like(y, -1), reduction="sum")
+    assert out.shape == g["allign_sum"].shape and torch.equal(out, g["allign_sum"])
+
+
+def test_g12_apgd_restarts():
+    g = load_golden("g12_apgd_restarts")
+    net = TinyConvNet(5, seed=12, gain=3.0)
+    noises = [g[f"noise_{i}"] for i in range(int(g["n_noise"]))]
+    xa, acc_last, acc = O.apgd_restarts(net, g["x"], g["y"], eps=g["eps"], n_iter=int(g["n_iter"]), loss="mask-ce-avg",
+                                        n_restarts=int(g["n_restarts"]), early_stop=True, track_loss="ce-avg",
+                                        use_rs=True, noises=noises)
+    assert torch.equal(acc, g["acc"]) and torch.equal(acc_last, g["acc_last"])
+    assert noises[1].shape[0] == 3          # the image that reached zero accuracy dropped out after restart 1
+    assert ((xa - g["x_adv"]).abs() > 1e-6).float().mean() <= 0.01
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g12_eval_performance(tag):
+    g = load_golden(f"g12_eval_performance_{tag}")
+    C = int(g["n_cls"])
+    net = TinyConvNet(C, seed=int(g["seed_net"]))
+    loader, s = [], 0
+    for n in g["sizes"].tolist():
+        loader.append((g["images"][s:s + n], g["targets"][s:s + n], "n"))
+        s += n
+    stats, l_out = O.eval_performance(net, loader, n_batches=int(g["n_batches"]), n_cls=C)
+    assert torch.equal(l_out, g["l_output"])
+    for k in ("mAcc", "aAcc", "mIoU"):
+        assert stats[k] == pytest.approx(g[k], rel=1e-6)

@@ -292,6 +292,15 @@ int sea_nchw_to_nhwc(const float* in, const float* scale, float* out, int B, int
 int sea_nhwc_to_nchw(const float* in, const float* scale, const float* residual, float* out, int B, int C,
                      int64_t HW, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Measurement probes (bench.py / tools/kernel_bench.py only; nothing on the product path calls them).
+ * sea_probe_stream_copy: dst[0:bytes] = src[0:bytes] with 16-byte-per-lane accesses (non_temporal != 0: nt loads and
+ *   stores): the HBM copy ceiling the roofline fractions are also quoted against ("report against a
+ *   measured stream ceiling on the box").  sea_probe_stream_read: read-only stream (sink: >= 2048 floats, untouched).
+ * bytes % 16 == 0, 16-byte aligned pointers. */
+int sea_probe_stream_copy(const void* src, void* dst, size_t bytes, int non_temporal, void* stream);
+int sea_probe_stream_read(const void* src, float* sink, size_t bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

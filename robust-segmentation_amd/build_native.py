@@ -28,6 +28,8 @@ SOURCES = [
     ("linf_kernels.hip", ["-ffp-contract=off"]),
     ("apgd_control.hip", ["-ffp-contract=off"]),
     ("loss_kernels.hip", []),
+    ("loss_stream.hip", []),
+    ("loss_split.hip", []),
     ("loss_upsampled.hip", []),
     ("stats_kernels.hip", []),
     ("dwconv_kernels.hip", []),
@@ -36,10 +38,11 @@ SOURCES = [
     ("wino_kernels.hip", []),
     ("ln_kernels.hip", []),
     ("fpn_fused.hip", []),
+    ("probe_kernels.hip", []),
     ("greedy_host.cpp", ["-ffp-contract=off"]),
     ("api_misc.cpp", []),
 ]
-HEADERS = ["sea_common.h", os.path.join("..", "..", "include", "sea_hip.h")]
+HEADERS = ["sea_common.h", "loss_common.h", os.path.join("..", "..", "include", "sea_hip.h")]
 
 
 def _hipcc() -> str:

@@ -13,128 +13,9 @@
 // Per-image sums (loss, tracking loss, #correct) are reduced wave -> block with shuffles + LDS and
 // written as one record per block; a second tiny kernel sums the records of an image in a fixed
 // order in double precision.  No float atomics => bitwise run-to-run determinism.
-#include "sea_common.h"
-
-#include <hip/hip_bf16.h>
-#include <hip/hip_fp16.h>
+#include "loss_common.h"
 
 namespace sea {
-
-constexpr float kLn2 = 0.69314718055994530942f;
-
-struct __attribute__((aligned(16))) BlockPartial {
-  float loss, track;
-  int n_correct, pad;
-};
-
-// ---- element conversion -------------------------------------------------------------------
-// logits travel as raw bits (float, or 16-bit patterns for bf16/f16) so that vector loads/stores can
-// use address-space-qualified ext-vector types.
-template <typename T>
-struct Elem;
-template <>
-struct Elem<float> {
-  using raw = float;
-  static __device__ __forceinline__ float to_f(raw v) { return v; }
-  static __device__ __forceinline__ raw from_f(float v) { return v; }
-};
-template <>
-struct Elem<__hip_bfloat16> {
-  using raw = unsigned short;
-  static __device__ __forceinline__ float to_f(raw v) { return __uint_as_float(((unsigned int)v) << 16); }
-  static __device__ __forceinline__ raw from_f(float v) {
-    const __hip_bfloat16 h = __float2bfloat16(v);  // round-to-nearest-even, NaN preserving
-    return __builtin_bit_cast(unsigned short, h);
-  }
-};
-template <>
-struct Elem<__half> {
-  using raw = unsigned short;
-  static __device__ __forceinline__ float to_f(raw v) { return __half2float(__ushort_as_half(v)); }
-  static __device__ __forceinline__ raw from_f(float v) { return __half_as_ushort(__float2half(v)); }
-};
-
-template <typename R, int VEC>
-struct RawVec {
-  typedef R type __attribute__((ext_vector_type(VEC)));
-};
-template <typename R>
-struct RawVec<R, 1> {
-  typedef R type;
-};
-template <typename R, int VEC>
-__device__ __forceinline__ R vec_get(const typename RawVec<R, VEC>::type& p, int v) {
-  if constexpr (VEC == 1)
-    return p;
-  else
-    return p[v];
-}
-template <typename R, int VEC>
-__device__ __forceinline__ void vec_set(typename RawVec<R, VEC>::type& p, int v, R x) {
-  if constexpr (VEC == 1)
-    p = x;
-  else
-    p[v] = x;
-}
-
-template <typename T>
-using gptr = const __attribute__((address_space(1))) T*;
-template <typename T>
-using gptr_w = __attribute__((address_space(1))) T*;
-
-// per-pixel loss value for a mode; ce = lse - z_y, logp = z_y - lse (<= 0)
-__device__ __forceinline__ float loss_value(int mode, bool valid, bool correct, float ce, float logp, float py,
-                                            float l1p, float wy) {
-  switch (mode) {
-    case SEA_MODE_MASK_CE: return correct ? ce : 0.f;
-    case SEA_MODE_MASK_CE_BAL: return correct ? wy * ce : 0.f;
-    case SEA_MODE_JS: return valid ? (kLn2 + 0.5f * (py * logp - (1.f + py) * l1p)) : 0.f;
-    default: return valid ? ce : 0.f;
-  }
-}
-
-// gradient coefficient K: d loss / d z_c = K * (p_c - [c == y])   
-__device__ __forceinline__ float grad_coef(int mode, bool valid, bool correct, float logp, float py, float l1p,
-                                           float wy) {
-  if (mode == SEA_MODE_JS) return valid ? (-0.5f * (logp - l1p) * py) : 0.f;
-  if (mode == SEA_MODE_CE) return valid ? 1.f : 0.f;
-  return correct ? wy : 0.f;
-}
-
-// block reduction of the three per-thread sums and record write (fixed order, deterministic).
-// Workspace layout: record 0 is a header {tiles per image, images, 0, 0} written by block (0,0); the
-// per-block records follow, image-major.  The header lets the consumer (loss_finalize or the APGD
-// bookkeeping kernel K7) find its way without the host knowing which tiling the dispatcher chose.
-__device__ __forceinline__ void block_reduce_store(float ls, float ts, int nc, BlockPartial* ws) {
-  __shared__ float s_l[4], s_t[4];
-  __shared__ int s_n[4];
-  ls = wave_sum(ls);
-  ts = wave_sum(ts);
-  nc = wave_sum_i(nc);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane == 0) {
-    s_l[wave] = ls;
-    s_t[wave] = ts;
-    s_n[wave] = nc;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    BlockPartial p;
-    p.loss = (s_l[0] + s_l[1]) + (s_l[2] + s_l[3]);
-    p.track = (s_t[0] + s_t[1]) + (s_t[2] + s_t[3]);
-    p.n_correct = s_n[0] + s_n[1] + s_n[2] + s_n[3];
-    p.pad = 0;
-    ws[1 + (int64_t)blockIdx.y * gridDim.x + blockIdx.x] = p;
-    if (blockIdx.x == 0 && blockIdx.y == 0) {
-      BlockPartial hdr;
-      hdr.loss = 0.f;
-      hdr.track = 0.f;
-      hdr.n_correct = (int)gridDim.x;  // tiles per image
-      hdr.pad = (int)gridDim.y;        // images
-      ws[0] = hdr;
-    }
-  }
-}
 
 // ---- NCHW, class vector in registers ---------------------------------------------------------
 // grid = (tiles per image, B); block = 256 threads; tile = 256*VEC consecutive pixels of one image.
@@ -266,8 +147,7 @@ __global__ __launch_bounds__(256, (TUNE & 4) ? 4 : 1) void loss_nchw_reg(const T
 
   if (active) {
     if (pred != nullptr) {
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) store_index_rt(pred, pred_bytes, (int64_t)b * HW + px0 + v, amax[v]);
+      store_indices<VEC>(pred, pred_bytes, (int64_t)b * HW + px0, amax);
     }
     if (loss_px != nullptr) {
 #pragma unroll
@@ -480,27 +360,6 @@ __global__ __launch_bounds__(256) void loss_finalize(const BlockPartial* __restr
 }
 
 // ---- dispatch --------------------------------------------------------------------------------------
-struct LossArgs {
-  const void* logits;
-  const void* y;
-  int y_bytes;
-  const float* w;
-  int mode, track_mode, B, C;
-  int64_t HW;
-  float gscale;
-  void* dlogits;
-  void* pred;
-  int pred_bytes;
-  float* loss_px;
-  BlockPartial* partials;
-  hipStream_t s;
-  int force_vec;
-};
-
-static inline int tiles_for(int64_t HW, int vec) { return (int)((HW + 256 * vec - 1) / (256 * (int64_t)vec)); }
-// workspace is sized for the smallest tile (VEC=1)
-static inline int max_tiles(int64_t HW) { return tiles_for(HW, 1); }
-
 template <typename T, int CPAD, int VEC>
 static void launch_reg(const LossArgs& a) {
   dim3 grid(tiles_for(a.HW, VEC), a.B), block(256);
@@ -569,11 +428,20 @@ static int dispatch_nchw(const LossArgs& a, bool vec4_ok, bool vec2_ok, int* vec
   } while (0)
   // force_vec: low 4 bits 0 = heuristic, 1/2/4 = pixels per lane; bits 4.. = TUNE variant (fp32 C=21/151 only)
   const int fv = a.force_vec & 15;
-  int tune = a.force_vec >> 4;
+  int tune = (a.force_vec >> 4) & 15;
   // measured defaults (kernel_bench, MI355X): C=21 fp32 runs best with non-temporal loads+stores at 4
   // waves/SIMD (74 % of 8 TB/s vs 65 %), C=151 with non-temporal loads (69 % vs 67.6 %)
-  if (a.force_vec == 0 && sizeof(T) == 4 && a.dlogits) tune = (C == 21 && vec4_ok) ? 7 : (C == 151 ? 2 : 0);
+  if ((a.force_vec & 0xfff) == 0 && sizeof(T) == 4 && a.dlogits) tune = (C == 21 && vec4_ok) ? 7 : (C == 151 ? 2 : 0);
+  if ((a.force_vec & 0xfff) == 0 && sizeof(T) == 4 && !a.dlogits && C == 21 && vec4_ok) tune = 6;
   if (tune == 15) tune = 0;  // explicit "no tuning" for A/B runs
+  if (tune == 6 && !a.dlogits && sizeof(T) == 4 && C == 21 && vec4_ok) {  // no-gradient: nt loads, 4 waves/SIMD
+    dim3 grid(tiles_for(a.HW, 4), a.B), block(256);
+    hipLaunchKernelGGL((loss_nchw_reg<T, 21, 4, false, true, 6>), grid, block, 0, a.s, (const T*)a.logits, a.y,
+                       a.y_bytes, a.w, a.mode, a.track_mode, a.C, a.HW, a.gscale, (T*)nullptr, a.pred, a.pred_bytes,
+                       a.loss_px, a.partials);
+    *vec_used = 4;
+    return 0;
+  }
   if (tune && a.dlogits && sizeof(T) == 4) {
     dim3 block(256);
 #define SEA_TUNED(CP, V, TU)                                                                                         \
@@ -654,6 +522,23 @@ static int dispatch_dtype(const LossArgs& a, int layout, int* tiles_used) {
            (!a.dlogits || (((uintptr_t)a.dlogits) % bytes) == 0);
   };
   int vec = 1;
+  // force_vec bit 12: legacy register kernels only (A/B runs); bits 8..11: variant of the streaming kernel
+  const bool legacy = (a.force_vec & 0x1000) != 0;
+  constexpr int V16 = 16 / (int)sizeof(T);
+  // no gradient: beyond 32 classes the class vector no longer fits the registers at a useful occupancy -> streaming
+  // kernel (loss_stream.hip).  Measured cold (tools/k2_lab.py): C=151 fp32 200 us vs 225 us register kernel, bf16
+  // 130 us vs 165 us; at C=21 the register kernel (all 21 plane loads of a lane in flight at once) is as fast (fp32)
+  // or faster (16-bit: 28.5 vs 32.7 us) than the chunk pipeline, which pays one memory round trip per chunk.
+  const bool want_stream = a.C > 32 || ((a.force_vec >> 8) & 15) != 0;
+  if (!legacy && !a.dlogits && al(V16) && (a.force_vec & 15) == 0 && want_stream) {
+    launch_fwd<T>(a, (a.force_vec >> 8) & 15);
+    *tiles_used = tiles_for(a.HW, V16);
+    return 0;
+  }
+  // ADE-sized class vectors with gradient: split over the wave halves (loss_split.hip); variant 15 = skip (A/B runs)
+  if (!legacy && a.dlogits && (a.force_vec & 15) == 0 && ((a.force_vec >> 8) & 15) != 15 &&
+      dispatch_split<T>(a, tiles_used))
+    return 0;
   const int rc = dispatch_nchw<T>(a, al(4), al(2), &vec);
   *tiles_used = tiles_for(a.HW, vec);
   return rc;

@@ -61,7 +61,10 @@ __device__ __forceinline__ int load_label_rt(const void* y, int bytes, int64_t i
   }
 }
 
-// VEC consecutive labels starting at element i (one wave-uniform switch on the width)
+// VEC consecutive labels starting at element i (one wave-uniform switch on the width).  One-byte labels (what the
+// attack uses: labels are compacted to uint8 once per run) come as whole dwords when VEC % 4 == 0: one
+// global_load_dword(x2) per lane instead of VEC global_load_ubyte (8 extra memory instructions per lane next to
+// 21 plane loads were the largest fixed cost of the 16-bit kernels at C=21).
 template <int VEC>
 __device__ __forceinline__ void load_labels(const void* y, int bytes, int64_t i, int (&lab)[VEC]) {
   if (bytes == 8) {
@@ -74,6 +77,23 @@ __device__ __forceinline__ void load_labels(const void* y, int bytes, int64_t i,
 #pragma unroll
     for (int v = 0; v < VEC; ++v) lab[v] = load_label<2>(y, i + v);
   } else {
+    if constexpr (VEC % 4 == 0) {
+      // i % VEC == 0 for every caller (tile origins and H*W are multiples of VEC), so the alignment of the access
+      // is that of the base pointer: a wave-uniform test, no divergent fallback
+      if ((((uintptr_t)y) & 3) == 0) {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(reinterpret_cast<const unsigned char*>(y) + i);
+#pragma unroll
+        for (int g = 0; g < VEC / 4; ++g) {
+          const uint32_t w = p[g];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int v = (int)((w >> (8 * k)) & 0xffu);
+            lab[4 * g + k] = v == 255 ? -1 : v;
+          }
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int v = 0; v < VEC; ++v) lab[v] = load_label<1>(y, i + v);
   }
@@ -86,6 +106,23 @@ __device__ __forceinline__ void store_index_rt(void* p, int bytes, int64_t i, in
     case 2: ((short*)p)[i] = (short)v; break;
     default: ((unsigned char*)p)[i] = (unsigned char)v; break;
   }
+}
+
+// VEC consecutive indices (argmax map); one-byte outputs are packed into dword stores when VEC % 4 == 0
+template <int VEC>
+__device__ __forceinline__ void store_indices(void* p, int bytes, int64_t i, const int (&val)[VEC]) {
+  if constexpr (VEC % 4 == 0) {
+    if (bytes == 1 && (((uintptr_t)p) & 3) == 0) {  // i % VEC == 0 for every caller
+      uint32_t* q = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(p) + i);
+#pragma unroll
+      for (int g = 0; g < VEC / 4; ++g)
+        q[g] = (uint32_t)(val[4 * g] & 0xff) | ((uint32_t)(val[4 * g + 1] & 0xff) << 8) |
+               ((uint32_t)(val[4 * g + 2] & 0xff) << 16) | ((uint32_t)(val[4 * g + 3] & 0xff) << 24);
+      return;
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) store_index_rt(p, bytes, i + v, val[v]);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -61,6 +61,8 @@ _SIGS = {
     "sea_gate_scale": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _vp]),
     "sea_upsample_bilinear_nhwc_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i64, _vp]),
     "sea_upsample_bilinear_nhwc_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i64, _vp]),
+    "sea_probe_stream_copy": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "sea_probe_stream_read": (_i, [_vp, _vp, _sz, _vp]),
 }
 EXPORTS = tuple(_SIGS)
 
@@ -162,7 +164,8 @@ def logits_layout(logits: torch.Tensor):
         raise SeaNativeError("logits must be (B,C,H,W)")
     if logits.is_contiguous():
         return logits, LAYOUT_NCHW
-    if logits.is_contiguous(memory_format=torch.channels_last):
+    # the channels_last kernel stages 256 pixels x C classes in LDS (160 KB): beyond 159 classes go through NCHW
+    if logits.is_contiguous(memory_format=torch.channels_last) and 256 * (logits.shape[1] | 1) * 4 <= 160 * 1024 - 64:
         return logits, LAYOUT_NHWC
     return logits.contiguous(), LAYOUT_NCHW
 

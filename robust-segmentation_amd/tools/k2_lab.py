@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""A/B laboratory for the K2 loss kernels: variants interleaved in one process, timed COLD.
+
+    python robust-segmentation_amd/tools/k2_lab.py [--classes 21 151] [--dtypes float32 bfloat16] [--json out.json]
+
+Timing: every variant is launched back to back over a ring of independent (logits, dlogits) buffer sets whose total
+footprint exceeds 1.5 GB, so that no launch finds its inputs in the 256 MiB Infinity Cache ("cold", the honest HBM
+figure), bracketed by ONE pair of HIP events on the launch stream per round (no per-launch event gap).
+`hot` repeats the same buffers instead (what the kernel sees inside the attack loop right after the model wrote the
+logits).  Rounds of all variants are interleaved; the median over rounds is reported.
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "robust-segmentation_amd")]
+
+import torch  # noqa: E402
+
+from semseg import _native as N  # noqa: E402
+
+PEAK = 8000.0
+B, H, W = 8, 512, 512
+HW = H * W
+
+
+def make_set(C, dtype, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    logits = torch.randn(B, C, H, W, generator=g, device="cuda") * 3
+    y = torch.randint(0, C, (B, H, W), generator=g, device="cuda")
+    boost = (torch.rand(B, H, W, generator=g, device="cuda") < 0.7).float() * 6
+    logits.scatter_add_(1, y.unsqueeze(1), boost.unsqueeze(1))
+    return logits.to(dtype), y.to(torch.uint8)
+
+
+def run_case(C, dtype, grad, variants, rounds=9, hot=False):
+    s = torch.empty(0, dtype=dtype).element_size()
+    set_bytes = B * C * HW * s * (2 if grad else 1)
+    nsets = 1 if hot else max(2, -(-1600 * 2 ** 20 // set_bytes))
+    sets = []
+    for i in range(nsets):
+        lg, y8 = make_set(C, dtype, i)
+        sets.append((lg, y8, torch.empty_like(lg) if grad else None))
+    w = torch.rand(C, device="cuda")
+    pred = torch.empty(B, H, W, dtype=torch.uint8, device="cuda")
+    ws = N.loss_workspace(B, HW, "cuda")
+    reps = max(1, 24 // nsets)
+
+    def go(fv):
+        for _ in range(reps):
+            for lg, y8, dl in sets:
+                N.loss_fwd_bwd(lg, y8, w, 1, 3, 1.0 / HW, grad, pred=pred, workspace=ws, dlogits=dl, force_vec=fv)
+
+    for fv in variants.values():
+        go(fv)
+    torch.cuda.synchronize()
+    ts = {k: [] for k in variants}
+    for _ in range(rounds):
+        for k, fv in variants.items():
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            go(fv)
+            b.record()
+            torch.cuda.synchronize()
+            ts[k].append(a.elapsed_time(b) / (reps * nsets))
+    alg = B * HW * ((2 if grad else 1) * C * s + 16)      # SURVEY 8(d) figure (int64 label + pred)
+    moved = B * HW * ((2 if grad else 1) * C * s + 2)     # bytes the kernel really moves (uint8 label + pred)
+    out = []
+    for k, v in ts.items():
+        ms = sorted(v)[len(v) // 2]
+        out.append(dict(kernel=f"K2 C={C} {str(dtype)[6:]} {'+grad' if grad else 'no-grad'} [{k}]", state="hot" if hot else "cold",
+                        ms=ms, min_ms=min(v), algorithmic_MB=alg / 1e6, moved_MB=moved / 1e6,
+                        frac_8TBps_algorithmic=alg / (ms * 1e-3) / 1e9 / PEAK, frac_8TBps_moved=moved / (ms * 1e-3) / 1e9 / PEAK))
+        print(f"{out[-1]['kernel']:64s} {out[-1]['state']:4s} {ms * 1e3:8.1f} us  alg {out[-1]['frac_8TBps_algorithmic']:6.1%}"
+              f"  moved {out[-1]['frac_8TBps_moved']:6.1%} of 8 TB/s", flush=True)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--classes", type=int, nargs="+", default=[21, 151])
+    ap.add_argument("--dtypes", nargs="+", default=["float32", "bfloat16"])
+    ap.add_argument("--json", default=None)
+    ap.add_argument("--hot", action="store_true", help="also time the repeat-same-buffers state")
+    args = ap.parse_args()
+    N.lib()
+    LEG = 0x1000
+    res = []
+    # copy / read ceilings with the library's own probes (1 GiB, cold by size)
+    src = torch.empty(256 * 2 ** 20, dtype=torch.float32, device="cuda").normal_()
+    dst = torch.empty_like(src)
+    sink = torch.zeros(4096, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    L = N.lib()
+    probes = {
+        "probe copy float4 nt (1 GiB -> 1 GiB)": (lambda: L.sea_probe_stream_copy(src.data_ptr(), dst.data_ptr(), src.numel() * 4, 1, st), 2),
+        "probe copy float4 plain": (lambda: L.sea_probe_stream_copy(src.data_ptr(), dst.data_ptr(), src.numel() * 4, 0, st), 2),
+        "probe read float4 nt (1 GiB)": (lambda: L.sea_probe_stream_read(src.data_ptr(), sink.data_ptr(), src.numel() * 4, st), 1),
+        "torch copy_ (1 GiB -> 1 GiB)": (lambda: dst.copy_(src), 2),
+    }
+    for name, (fn, mult) in probes.items():
+        fn()
+        torch.cuda.synchronize()
+        t = []
+        for _ in range(7):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(4):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            t.append(a.elapsed_time(b) / 4)
+        ms = sorted(t)[3]
+        gbs = mult * src.numel() * 4 / (ms * 1e-3) / 1e9
+        res.append(dict(kernel=name, ms=ms, GBps=gbs, frac_8TBps=gbs / PEAK))
+        print(f"{name:64s}      {ms * 1e3:8.1f} us  {gbs:8.1f} GB/s  {gbs / PEAK:6.1%}", flush=True)
+    del src, dst
+    for C in args.classes:
+        for dn in args.dtypes:
+            dtype = getattr(torch, dn)
+            # no gradient: streaming variants vs the legacy register kernel
+            v = {"default": 0, "stream CH4/5w": 0x100, "stream CH8/3w": 0x200, "stream CH6/4w": 0x300,
+                 "stream CH2/8w": 0x400, "register kernel": LEG, "register kernel untuned": LEG | (15 << 4)}
+            for hot in ([False, True] if args.hot else [False]):
+                res += run_case(C, dtype, False, v, hot=hot)
+            # with gradient
+            if dtype == torch.float32:
+            v = {"default": 0, "register kernel": LEG, "register kernel untuned": LEG | (15 << 4)}
+            if C in (150, 151):
+                v.update({"split 5 waves": 0x100, "split 3 waves": 0x200, "split 4 waves": 0x300})
+            for hot in ([False, True] if args.hot else [False]):
+                res += run_case(C, dtype, True, v, hot=hot)
+    if args.json:
+        json.dump(res, open(args.json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

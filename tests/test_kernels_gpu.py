@@ -179,8 +179,12 @@ def test_loss_kernel_no_grad_variant_and_determinism(N):
     a = N.loss_fwd_bwd(dev(logits), dev(y), dev(w), 1, 3, 1.0 / 4096, want_grad=False)
     b = N.loss_fwd_bwd(dev(logits), dev(y), dev(w), 1, 3, 1.0 / 4096, want_grad=True)
     assert a["dlogits"] is None
-    for k in ("loss_sum", "track_sum", "n_correct"):
-        assert torch.equal(a[k], b[k])
+    # the no-gradient pass is a different kernel (streaming online soft-max): same integers, float sums to rounding
+    assert torch.equal(a["n_correct"], b["n_correct"])
+    for k in ("loss_sum", "track_sum"):
+        torch.testing.assert_close(a[k], b[k], rtol=2e-6, atol=0)
+    a2 = N.loss_fwd_bwd(dev(logits), dev(y), dev(w), 1, 3, 1.0 / 4096, want_grad=False)
+    assert all(torch.equal(a[k], a2[k]) for k in ("loss_sum", "track_sum", "n_correct"))   # run-to-run deterministic
     c = N.loss_fwd_bwd(dev(logits), dev(y), dev(w), 1, 3, 1.0 / 4096, want_grad=True)
     assert torch.equal(b["dlogits"], c["dlogits"]) and torch.equal(b["loss_sum"], c["loss_sum"])
 
@@ -850,3 +854,100 @@ def test_convnext_block_frozen_weights_fold_layer_scale(N):
     fast2, ref2 = run(True), run(False)
     torch.testing.assert_close(fast2[0], ref2[0], rtol=2e-4, atol=2e-4 * ref2[0].abs().max().item())
     assert not torch.allclose(fast2[0], fast[0])
+
+
+# ------------------------------------------------------------------------------------------------ full-size ADE workloads
+def _ade_case(b, seed, C=151, H=512, W=512, dtype=torch.float32):
+    """one image of the SURVEY 8(d) micro-benchmark distribution (generated per image to bound host memory)"""
+    g = torch.Generator().manual_seed(seed * 131 + b)
+    logits = torch.randn(1, C, H, W, generator=g) * 3
+    y = torch.randint(0, C, (1, H, W), generator=g)
+    boost = (torch.rand(1, H, W, generator=g) < 0.7).float() * 6
+    logits.scatter_add_(1, y.unsqueeze(1), boost.unsqueeze(1))
+    y[torch.rand(1, H, W, generator=g) < 0.03] = -1
+    return logits.to(dtype), y
+
+
+@pytest.mark.parametrize("dtype,mode", [(torch.float32, 1), (torch.float32, 2), (torch.bfloat16, 1)])
+def test_loss_kernel_full_size_ade_batch(N, dtype, mode):
+    """BASELINE configs[2..4] size: 8 x 151 x 512 x 512 (1.27 GB of fp32 logits and as much gradient per launch; the
+    238-VGPR one-pixel-per-lane instantiation at its full grid).  Ints exact, losses 1e-4, gradient element-wise;
+    the oracle runs image by image on the host."""
+    from semseg.utils.utils import ADE_WTS
+    B, C, H, W = 8, 151, 512, 512
+    HW = H * W
+    w = torch.tensor(ADE_WTS)
+    imgs = [_ade_case(b, 9, dtype=dtype) for b in range(B)]
+    logits = torch.cat([i[0] for i in imgs]).cuda()
+    y = torch.cat([i[1] for i in imgs])
+    y8 = torch.where(y < 0, torch.full_like(y, 255), y).to(torch.uint8).cuda()
+    pred = torch.empty(B, H, W, dtype=torch.uint8, device="cuda")
+    r = N.loss_fwd_bwd(logits, y8, w.cuda(), mode, 3, 1.0 / HW, want_grad=True, pred=pred)
+    r0 = N.loss_fwd_bwd(logits, y8, w.cuda(), mode, 3, 1.0 / HW, want_grad=False,
+                        pred=torch.empty_like(pred))                       # the no-gradient variant, same sums
+    torch.cuda.synchronize()
+    assert torch.equal(r["n_correct"], r0["n_correct"]) and torch.equal(r0["pred"], pred)
+    for k in ("loss_sum", "track_sum"):
+        torch.testing.assert_close(r[k], r0[k], rtol=1e-5, atol=0)
+    del logits
+    for b in range(B):
+        lg, yb = imgs[b]
+        ref = O.loss_fwd_bwd(lg.float(), yb, w, mode, 3, with_grad=True)
+        assert torch.equal(pred[b].cpu().long(), ref["pred"][0])
+        assert int(r["n_correct"][b]) == int(ref["n_correct"][0])
+        assert (r["loss_sum"][b] / HW).item() == pytest.approx(ref["loss_img"][0].item(), rel=1e-4, abs=1e-6)
+        assert (r["track_sum"][b] / HW).item() == pytest.approx(ref["track_img"][0].item(), rel=1e-4, abs=1e-6)
+        got = r["dlogits"][b].float().cpu()
+        tol = dict(rtol=1e-4, atol=2e-8 + 1e-6 / HW) if dtype == torch.float32 else dict(rtol=2e-2, atol=1e-2 / HW)
+        torch.testing.assert_close(got, ref["dlogits"][0], **tol)
+        # size-independent: soft-max gradient rows sum to zero (to the rounding of the output type)
+        assert got.sum(0).abs().max().item() < (1e-9 if dtype == torch.float32 else 2e-7)
+
+
+@pytest.mark.parametrize("case", [(151, 32, 512, "Segmenter x16"), (151, 128, 512, "UperNet x4"), (21, 128, 512, "UperNet x4")])
+def test_fused_upsample_loss_kernel_full_size(N, case):
+    """K2u at the BASELINE sizes: 8 x C x (32|128)^2 low-res logits -> 512^2 labels."""
+    C, hl, HH, _ = case
+    B = 8
+    g = torch.Generator().manual_seed(C + hl)
+    low = torch.randn(B, C, hl, hl, generator=g) * 3
+    wts = torch.rand(C, generator=g) + 0.01
+    ys = []
+    for b in range(B):   # labels: the interpolated argmax with 30 % flips and 3 % ignored
+        yb = torch.nn.functional.interpolate(low[b:b + 1], size=(HH, HH), mode="bilinear", align_corners=False).max(1)[1]
+        flip = torch.rand(1, HH, HH, generator=g) < 0.3
+        yb[flip] = torch.randint(0, C, (int(flip.sum()),), generator=g)
+        yb[torch.rand(1, HH, HH, generator=g) < 0.03] = -1
+        ys.append(yb)
+    y = torch.cat(ys)
+    pred = torch.empty(B, HH, HH, dtype=torch.int64, device="cuda")
+    r = N.loss_fwd_bwd_upsampled(low.cuda(), y.cuda(), wts.cuda(), 1, 3, 1.0 / (HH * HH), want_grad=True, pred=pred)
+    torch.cuda.synchronize()
+    for b in range(B):
+        ref = O.loss_fwd_bwd_upsampled(low[b:b + 1], y[b:b + 1], wts, 1, 3, with_grad=True)
+        top2 = ref["logits_hi"].topk(2, dim=1)[0]
+        safe = (top2[:, 0] - top2[:, 1]) > 1e-4
+        assert torch.equal(pred[b:b + 1].cpu()[safe], ref["pred"][safe])
+        assert abs(int(r["n_correct"][b]) - int(ref["n_correct"][0])) <= int((~safe).sum())
+        assert (r["loss_sum"][b] / (HH * HH)).item() == pytest.approx(ref["loss_img"][0].item(), rel=1e-4, abs=1e-6)
+        assert (r["track_sum"][b] / (HH * HH)).item() == pytest.approx(ref["track_img"][0].item(), rel=1e-4, abs=1e-6)
+        scale = ref["dlow"].abs().max().item()
+        torch.testing.assert_close(r["dlogits"][b:b + 1].cpu(), ref["dlow"], rtol=2e-3, atol=2e-4 * scale + 1e-9)
+
+
+def test_counts_full_size_ade(N):
+    """K3 at C=151, 8 x 512 x 512: per-image tables and the confusion matrix, exact."""
+    C, shape = 151, (8, 512, 512)
+    g = torch.Generator().manual_seed(5)
+    y = torch.randint(0, C, shape, generator=g)
+    pred = torch.where(torch.rand(shape, generator=g) < 0.6, y, torch.randint(0, C, shape, generator=g))
+    y[torch.rand(shape, generator=g) < 0.04] = -1
+    y[y == 150] = 3                                                         # an absent class
+    for mask_pred in (True, False):
+        ref = O.class_counts(pred, y, C, per_image=True, mask_pred=mask_pred)
+        y8 = torch.where(y < 0, torch.full_like(y, 255), y).to(torch.uint8)
+        got = N.class_counts(pred.to(torch.uint8).cuda(), y8.cuda(), C, per_image=True, mask_pred=mask_pred)
+        for a, b in zip(got, ref):
+            assert torch.equal(a.cpu(), b)
+    hist = N.confusion(pred.cuda(), y.cuda(), C)
+    assert torch.equal(hist.cpu(), O.confusion_matrix(pred, y, C))

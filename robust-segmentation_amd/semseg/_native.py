@@ -93,9 +93,18 @@ def _check(rc: int, what: str):
 
 
 def _dev(*ts):
+    """Every kernel is launched on the CURRENT stream of the CURRENT device, so all tensors must live there."""
+    cur = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise SeaNativeError("libsea_hip works on HIP device tensors only (no CPU fallback); got a CPU tensor")
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise SeaNativeError(f"tensor on {t.device} but the current device is cuda:{cur}: call "
+                                 "torch.cuda.set_device (or use `with torch.cuda.device(...)`) before the launch")
 
 
 def _stream() -> int:

@@ -145,10 +145,18 @@ class _DwConv7x7NHWC(torch.autograd.Function):
         return gx, gw, gb, None
 
 
+def _tkey(*ts):
+    """Cache key of weights derived from the tensors ``ts``: object identity, storage address, in-place version and
+    device of every source.  The identity term covers a parameter that was REPLACED by a fresh tensor which happens
+    to reuse a freed address at version 0 (``module.weight = nn.Parameter(...)``, a re-materialised model), and the
+    caches copied along by ``copy.deepcopy`` (new parameter objects -> new key); ``.to()`` changes address / device."""
+    return tuple((id(t), t.data_ptr(), t._version, str(t.device)) for t in ts if t is not None)
+
+
 def _taps_major(conv: nn.Conv2d):
     """(49, C) copy of the depthwise filter bank, cached until the weight changes."""
     w = conv.weight
-    key = (w.data_ptr(), w._version, w.device)
+    key = _tkey(w)
     cached = getattr(conv, "_sea_wt", None)
     if cached is None or cached[0] != key:
         cached = (key, w.detach().reshape(w.shape[0], 49).t().contiguous())
@@ -255,7 +263,7 @@ class Block(nn.Module):
             w2, b2, g = self.pwconv2.weight, self.pwconv2.bias, self.gamma
             if g is not None and not (w2.requires_grad or g.requires_grad or (b2 is not None and b2.requires_grad)):
                 # frozen weights: the layer scale is folded into the second projection (one kernel less each way)
-                key = tuple((t.data_ptr(), t._version) for t in (w2, b2, g) if t is not None)
+                key = _tkey(w2, b2, g)
                 cache = self.__dict__.setdefault("_fold_cache", {})
                 if cache.get("key") != key:
                     with torch.no_grad():
@@ -344,7 +352,7 @@ class _WinoConv3x3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, m, cache, scale, shift, relu):
         from .. import _native as N
-        key = (weight.data_ptr(), weight._version, m)
+        key = (_tkey(weight), m)
         if cache.get("key") != key:
             cache.update(key=key, fwd=N.wino_filter(weight.contiguous(), m, False), bwd=None)
         ctx.cache, ctx.m, ctx.weight, ctx.relu = cache, m, weight, relu
@@ -368,7 +376,7 @@ class _WinoConv3x3(torch.autograd.Function):
 def _folded_bn(bn, conv_bias, cache):
     """eval-mode BatchNorm as y = scale[c] * x + shift[c] (cached until a buffer / parameter changes)"""
     ts = (bn.weight, bn.bias, bn.running_mean, bn.running_var, conv_bias)
-    key = tuple((t.data_ptr(), t._version) for t in ts if t is not None)
+    key = _tkey(*ts)
     if cache.get("bn_key") != key:
         with torch.no_grad():
             scale = torch.rsqrt(bn.running_var + bn.eps)
@@ -420,7 +428,7 @@ class ConvModule(nn.Module):
             object.__setattr__(self, "_wino_cache", {})
         cache, w = self._wino_cache, self.conv.weight
         scale, shift = _folded_bn(self.batch_norm, self.conv.bias, cache)
-        key = (w.data_ptr(), w._version, cache["bn_key"])
+        key = (_tkey(w), cache["bn_key"])
         if cache.get("pw_key") != key:
             with torch.no_grad():
                 cache.update(pw_key=key, pw_w=(w.view(w.shape[0], -1) * scale[:, None]).contiguous())
@@ -588,7 +596,7 @@ class _FpnBottleneck(torch.autograd.Function):
         offs = [sum(chans[:i]) for i in range(len(fs))]
         hi = [i for i, f in enumerate(fs) if i == 0 or H / f.shape[2] < LOWRES_MIN_FACTOR or W / f.shape[3] < LOWRES_MIN_FACTOR]
         lo = [i for i in range(len(fs)) if i not in hi]
-        key = (weight.data_ptr(), weight._version, m, tuple(hi), tuple(chans))
+        key = (_tkey(weight), m, tuple(hi), tuple(chans))
         if cache.get("fpn_key") != key:
             w_hi = torch.cat([weight[:, offs[i]:offs[i] + chans[i]] for i in hi], 1).contiguous()
             cache.update(fpn_key=key, fpn_fwd=N.wino_filter(w_hi, m, False), fpn_bwd=N.wino_filter(w_hi, m, True),

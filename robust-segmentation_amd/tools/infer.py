@@ -220,6 +220,7 @@ def main(argv=None):
                     help="write argmax-logs/{model}_{loss}_{eps}.pt (the reference always does, infer.py:366-370)")
     ap.add_argument("--json", type=str, default=None)
     ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--dump_stats", type=str, default=None, help="save the all-reduced packed statistics buffer (rank 0)")
     args = ap.parse_args(argv)
 
     with open(args.cfg) as f:
@@ -286,6 +287,18 @@ def main(argv=None):
         rows = local_rows(idx)
         return images[rows].to(device, non_blocking=True), rows
 
+    def start_noise(idx, a):
+        """Uniform draws of the three random starts (one per apgd_largereps stage), one stream PER IMAGE keyed by
+        (seed, global image index, attack): the evaluation does not depend on how images are batched or sharded
+        (the reference consumes one global stream batch by batch, tools/infer.py:25-30)."""
+        out = [torch.empty(len(idx), 3, H, W, device=device) for _ in range(3)]
+        gen = torch.Generator(device=device)
+        for j, gi in enumerate(idx):
+            gen.manual_seed(SEED * 1000003 + gi * 7 + a)
+            for st in range(3):
+                out[st][j] = torch.rand(3, H, W, generator=gen, device=device)
+        return out
+
     # ---- clean pass (tools/infer.py:314-322) ------------------------------------------------------
     clean_tot = tuple(stats.clean[k] for k in range(3))
     for idx in batches:
@@ -308,7 +321,7 @@ def main(argv=None):
         for idx in batches:
             x, rows = batch_to_device(idx)
             y = labels_h[rows].to(device).long().contiguous()
-            x_adv, _, acc, pred = attack_fn(model, x, y, weights, return_pred=True)
+            x_adv, _, acc, pred = attack_fn(model, x, y, weights, return_pred=True, noises=start_noise(idx, a))
             # predictions masked at ignored pixels, like the logs eval_performance hands to evalSEA (infer.py:88-90)
             im, pm, tc = N.class_counts(pred, y, C, per_image=True, mask_pred=True)
             stats.add_attack_batch(a, idx, im, pm, tc)
@@ -319,6 +332,8 @@ def main(argv=None):
 
     # ---- the ONE collective, then host-side worst-case bookkeeping on rank 0 ----------------------------
     stats.all_reduce()
+    if args.dump_stats and rank == 0:
+        torch.save(stats.buf.cpu(), args.dump_stats)
     summary = None
     if rank == 0:
         s = stats.cpu()

@@ -70,7 +70,12 @@ class SeaStats:
     # ---- the one collective ----------------------------------------------------------------------
     def all_reduce(self):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM)
+            if self.buf.is_cuda and dist.get_backend() == "gloo":  # single-GPU test set-ups: reduce through the host
+                host = self.buf.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                self.buf.copy_(host)
+            else:
+                dist.all_reduce(self.buf, op=dist.ReduceOp.SUM)
         return self
 
     def cpu(self) -> "SeaStats":

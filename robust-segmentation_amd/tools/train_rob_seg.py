@@ -81,7 +81,7 @@ def build_attack(train_cfg):
         return lambda model, img, lbl: atk.adv_attack(model, img, lbl)[0]
     return lambda model, img, lbl: attacker.apgd_train(model, img, lbl, norm="Linf", eps=eps, n_iter=n, use_rs=True,
                                                        loss="ce-avg", track_loss=None,
-                                                       num_classes=int(train_cfg.get("N_CLS", 21)))[3]
+                                                       num_classes=int(train_cfg.get("N_CLS", 21)))[0]  # x_best, as the reference (train_rob_seg.py:336)
 
 
 def main(argv=None):
@@ -94,6 +94,12 @@ def main(argv=None):
     ap.add_argument("--batch_size", type=int, default=None)
     ap.add_argument("--bf16", action="store_true")
     ap.add_argument("--json", type=str, default=None)
+    ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI)")
+    ap.add_argument("--emulate_ranks", type=int, default=0,
+                    help="single process standing in for N data-parallel ranks: every step runs the N ranks' batches "
+                         "one after the other from the same weights and averages their gradients (what DDP's "
+                         "all-reduce computes); used to check the multi-rank run")
+    ap.add_argument("--dump_params", type=str, default=None, help="save a few parameter tensors after the last step")
     args = ap.parse_args(argv)
     with open(args.cfg) as f:
         cfg = yaml.load(f, Loader=yaml.SafeLoader)
@@ -104,11 +110,11 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    dev = torch.device("cuda", local)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+    dev = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
+    torch.cuda.set_device(dev)
     torch.backends.cudnn.benchmark = True
     torch.manual_seed(0)
 
@@ -121,16 +127,22 @@ def main(argv=None):
     else:
         raise ValueError(model_cfg["NAME"])
     model = model.to(dev)
-    ddp = DDP(model, device_ids=[local]) if world > 1 else model
+    ddp = DDP(model, device_ids=[dev.index]) if world > 1 else model
     core = model  # the attack always runs on the un-wrapped module: no collective inside the inner loop
 
-    bs = args.batch_size or int(train_cfg["BATCH_SIZE"]) // max(world, 1)
+    virt = max(args.emulate_ranks, 1)  # data-parallel ranks this process stands in for
+    bs = args.batch_size or int(train_cfg["BATCH_SIZE"]) // max(world * virt, 1)
     size = int(train_cfg["IMAGE_SIZE"][0])
     size -= size % 32  # synthetic crops: multiples of 32 keep every feature map integral
-    g = torch.Generator().manual_seed(1234 + rank)
     n = max(args.synthetic, bs)
-    images = torch.rand(n, 3, size, size, generator=g)
-    labels = torch.randint(0, C, (n, size // 32, size // 32), generator=g).repeat_interleave(32, 1).repeat_interleave(32, 2)
+
+    def rank_data(r):
+        g = torch.Generator().manual_seed(1234 + r)
+        im = torch.rand(n, 3, size, size, generator=g)
+        lb = torch.randint(0, C, (n, size // 32, size // 32), generator=g).repeat_interleave(32, 1).repeat_interleave(32, 2)
+        return im, lb
+
+    data = [rank_data(rank * virt + v) for v in range(virt)]
 
     opt = get_optimizer(ddp, cfg["OPTIMIZER"]["NAME"], cfg["OPTIMIZER"]["LR"], cfg["OPTIMIZER"]["WEIGHT_DECAY"])
     total = args.steps + args.warmup
@@ -142,21 +154,40 @@ def main(argv=None):
 
     def one_step(i):
         idx = [(i * bs + j) % n for j in range(bs)]
-        img, lbl = images[idx].to(dev, non_blocking=True), labels[idx].to(dev, non_blocking=True)
         opt.zero_grad(set_to_none=True)
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
-            if attack_fn is not None:
-                core.eval()
-                img = attack_fn(core, img, lbl)
-                core.train()
-            if model_cfg["NAME"] == "UperNetForSemanticSegmentation":
-                loss, _ = ddp(img, lbl)
-            else:
-                loss = torch.nn.functional.cross_entropy(ddp(img), lbl, ignore_index=-1)
-        loss.backward()      # DDP all-reduces the gradient buckets here: the step's only collective
+        first = None
+        # emulated ranks: every rank starts the step from the same buffers (BatchNorm running statistics feed the
+        # eval-mode inner attack), and rank 0's buffers are the ones that survive (DDP broadcasts them)
+        buf0 = [b.clone() for b in core.buffers()] if virt > 1 else None
+        buf_r0 = None
+        for v, (images, labels) in enumerate(data):
+            if v > 0:
+                if buf_r0 is None:
+                    buf_r0 = [b.clone() for b in core.buffers()]
+                for b, b0 in zip(core.buffers(), buf0):
+                    b.copy_(b0)
+            img, lbl = images[idx].to(dev, non_blocking=True), labels[idx].to(dev, non_blocking=True)
+            # the random start of the inner attack: one stream per (data-parallel rank, step), whoever runs it
+            torch.cuda.manual_seed(1000003 * (rank * virt + v) + i)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                if attack_fn is not None:
+                    core.eval()
+                    img = attack_fn(core, img, lbl)
+                    core.train()
+                if model_cfg["NAME"] == "UperNetForSemanticSegmentation":
+                    loss, _ = ddp(img, lbl)
+                else:
+                    loss = torch.nn.functional.cross_entropy(ddp(img), lbl, ignore_index=-1)
+            # DDP all-reduces (averages) the gradient buckets in backward: the step's only collective.  Emulated
+            # ranks accumulate loss / virt instead, which is the same average.
+            (loss / virt if virt > 1 else loss).backward()
+            first = loss.detach() if first is None else first
+        if buf_r0 is not None:
+            for b, b0 in zip(core.buffers(), buf_r0):
+                b.copy_(b0)
         opt.step()
         sched.step()
-        return loss.detach()
+        return first
 
     for i in range(args.warmup):
         one_step(i)
@@ -180,6 +211,10 @@ def main(argv=None):
         print(json.dumps(out))
         if args.json:
             json.dump(out, open(args.json, "w"))
+        if args.dump_params:
+            sd = core.state_dict()
+            keep = [k for k in sd if k.endswith(("gamma", "weight")) and sd[k].dtype == torch.float32][:: max(len(sd) // 24, 1)]
+            torch.save({k: sd[k].detach().cpu() for k in keep}, args.dump_params)
     if world > 1:
         dist.destroy_process_group()
 

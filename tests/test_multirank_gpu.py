@@ -1,0 +1,95 @@
+"""Multi-rank paths on ONE GPU (`-m gpu`): the ranks are fresh child processes started with torch.distributed.run
+(the test process itself never re-execs), the backend is gloo because one device cannot host two RCCL ranks; on a
+multi-GPU node the same code runs with "nccl" = RCCL, one GPU per rank.
+
+  * tools.infer sharded over 2 ranks: the all-reduced packed statistics buffer equals the 1-rank run bit for bit;
+  * tools.train_rob_seg under 2-rank DDP: the step equals one process that runs both ranks' batches and averages
+    their gradients (what the gradient all-reduce computes): reference tools/train_rob_seg.py:143-145, 164-169;
+  * bench.py --gpus 2 starts its two ranks by itself and reports the world size the collective library saw."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import PKG, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _torchrun(n, module_args, cwd=PKG, extra_env=None, timeout=1500):
+    env = dict(os.environ, PYTHONPATH=PKG + os.pathsep + os.environ.get("PYTHONPATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(extra_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + module_args
+    r = subprocess.run(cmd, cwd=cwd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-3000:]
+    return r
+
+
+def _cfg(tmp_path, name, **train):
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(PKG, "configs", name)))
+    cfg["SAVE_DIR"] = str(tmp_path) + "/"
+    cfg["TRAIN"].update(train)
+    p = str(tmp_path / "cfg.yaml")
+    yaml.safe_dump(cfg, open(p, "w"))
+    return p
+
+
+def test_sharded_sea_eval_two_ranks_equal_one_rank(tmp_path):
+    from tools import infer
+    cfg = _cfg(tmp_path, "pascalvoc_convnext.yaml")
+    common = ["--cfg", cfg, "--eps", "8", "--n_iter", "10", "--synthetic", "6", "--image_size", "64", "--batch_size", "2",
+              "--cleanup", "0"]
+    one = str(tmp_path / "one.pt")
+    s1 = infer.main(common + ["--dump_stats", one])
+    two, js = str(tmp_path / "two.pt"), str(tmp_path / "two.json")
+    _torchrun(2, ["-m", "tools.infer"] + common + ["--backend", "gloo", "--dump_stats", two, "--json", js])
+    a, b = torch.load(one), torch.load(two)
+    assert a.dtype == torch.int64 and torch.equal(a, b)          # integer tables: independent of the sharding
+    s2 = json.load(open(js))
+    assert s2["world"] == 2 and s2["n_images"] == 6
+    for k in ("worst_Acc", "final_miou", "loss-wise_miou", "clean"):
+        assert s1[k] == s2[k], k
+
+
+def test_ddp_two_ranks_equal_gradient_average_of_one_process(tmp_path):
+    cfg = _cfg(tmp_path, "pascalvoc_convnext.yaml", IMAGE_SIZE=[64, 64], N_ITERS=2)
+    common = ["--cfg", cfg, "--synthetic", "4", "--steps", "2", "--warmup", "0", "--batch_size", "2"]
+    p2, j2 = str(tmp_path / "p2.pt"), str(tmp_path / "j2.json")
+    _torchrun(2, ["-m", "tools.train_rob_seg"] + common + ["--backend", "gloo", "--dump_params", p2, "--json", j2])
+    from tools import train_rob_seg
+    p1, j1 = str(tmp_path / "p1.pt"), str(tmp_path / "j1.json")
+    train_rob_seg.main(common + ["--emulate_ranks", "2", "--dump_params", p1, "--json", j1])
+    a, b = torch.load(p1), torch.load(p2)
+    assert a.keys() == b.keys() and len(a) >= 8
+    for k in a:
+        torch.testing.assert_close(b[k], a[k], rtol=2e-4, atol=2e-6, msg=k)   # two optimizer steps later
+    o1, o2 = json.load(open(j1)), json.load(open(j2))
+    assert o2["world"] == 2 and o1["world"] == 1
+    assert o2["last_loss"] == pytest.approx(o1["last_loss"], rel=2e-3)           # rank 0's batch loss of the last step
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher environment: the parent spawns the ranks as child processes and
+    the JSON line carries the world size the collective library reported (gloo here: two ranks share the one GPU)."""
+    env = dict(os.environ, SEA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "2", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["scaling"] == "weak"
+    assert out["roofline"]["frac_cold"] is not None and out["roofline"]["measured_copy_ceiling_GBps"] > 1000

@@ -286,6 +286,41 @@ class Block(nn.Module):
         return x + self.drop_path(y.permute(0, 3, 1, 2))
 
 
+class _PatchConv2x2(torch.autograd.Function):
+    """2x2 / stride-2 convolution with frozen weights (the three down-sampling layers of the trunk,
+    reference convnext_orig.py:118-124) as ONE GEMM on the 2x2 patches: y[b,i,j,:] = W (Cout, 2*2*C) . patch(b,i,j).
+    MIOpen's kernel for this shape accumulates with atomics: its output differs in the last bit from run to run,
+    which made whole attacks irreproducible (and dependent on how images were batched or sharded).  The GEMM is
+    bitwise reproducible; input and output are channels_last, the patch gather is one strided copy each way."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cache):
+        B, C, H, W = x.shape
+        key = _tkey(weight)
+        if cache.get("key") != key:
+            cache.update(key=key, w=weight.detach().permute(0, 2, 3, 1).reshape(weight.shape[0], 4 * C).contiguous())
+        wr = cache["w"]                                                        # (Cout, (di, dj, c))
+        patches = x.permute(0, 2, 3, 1).reshape(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, 4 * C)
+        y = torch.addmm(bias, patches, wr.t()) if bias is not None else patches @ wr.t()
+        ctx.wr, ctx.shape = wr, (B, C, H, W)
+        return y.view(B, H // 2, W // 2, -1).permute(0, 3, 1, 2)               # channels_last (B,Cout,H/2,W/2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        B, C, H, W = ctx.shape
+        g = gy.permute(0, 2, 3, 1).reshape(-1, gy.shape[1])
+        gp = (g @ ctx.wr).view(B, H // 2, W // 2, 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, C)
+        return gp.permute(0, 3, 1, 2), None, None, None
+
+
+def _patch_conv_ok(conv, x):
+    return (USE_HIP_DWCONV and isinstance(conv, nn.Conv2d) and conv.kernel_size == (2, 2) and conv.stride == (2, 2)
+            and conv.padding == (0, 0) and conv.groups == 1 and x.is_cuda and x.dtype == torch.float32
+            and conv.weight.dtype == torch.float32 and not torch.is_autocast_enabled()
+            and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+            and not (conv.weight.requires_grad or (conv.bias is not None and conv.bias.requires_grad)))
+
+
 class ConvNeXt(nn.Module):
     def __init__(self, strr: str, in_chans: int = 3, layer_scale_init_value: float = 1.0, out_indices=(0, 1, 2, 3)):
         super().__init__()
@@ -324,7 +359,11 @@ class ConvNeXt(nn.Module):
     def forward(self, x):
         feats = []
         for i in range(4):
-            x = self.downsample_layers[i](x)
+            ds = self.downsample_layers[i]
+            if i > 0 and _patch_conv_ok(ds[1], x):
+                x = _PatchConv2x2.apply(ds[0](x), ds[1].weight, ds[1].bias, ds[1].__dict__.setdefault("_patch_cache", {}))
+            else:
+                x = ds(x)
             if STAGE_ENTRY_CONTIGUOUS and not x.is_contiguous():
                 x = x.contiguous()  # the blocks' stencil / transpose kernels want NCHW planes
             x = self.stages[i](x)
@@ -671,6 +710,23 @@ class PyramidPooling(nn.Module):
         return [_up(p, x.shape[2:]) for p in self.pooled(x)]
 
 
+def _classify(conv: nn.Conv2d, y):
+    """The head's final 1x1 convolution (uperforseg.py:262).  For frozen fp32 weights and a dense channels_last
+    input it runs as one batched GEMM  W (cls, Cin) @ y_b^T (Cin, H*W)  whose output IS the NCHW logit tensor the
+    loss kernel wants (no layout copy), bitwise reproducible; MIOpen's kernel for this shape is not (run-to-run
+    differences in the last bit of the logits)."""
+    from .. import _native as N
+    if (y.is_cuda and y.dtype == torch.float32 and conv.kernel_size == (1, 1) and not torch.is_autocast_enabled()
+            and not conv.weight.requires_grad and (conv.bias is None or not conv.bias.requires_grad)
+            and N.cl_pixel_stride(y) == y.shape[1]):
+        B, Cin, H, W = y.shape
+        out = torch.matmul(conv.weight.view(conv.out_channels, Cin), y.permute(0, 2, 3, 1).reshape(B, H * W, Cin).transpose(1, 2))
+        if conv.bias is not None:
+            out = out + conv.bias.view(1, -1, 1)
+        return out.view(B, conv.out_channels, H, W)
+    return conv(y)
+
+
 class UperNetHead(nn.Module):
     def __init__(self, in_channels, cls, channels: int = 512, pool_scales=(1, 2, 3, 6)):
         super().__init__()
@@ -700,7 +756,7 @@ class UperNetHead(nn.Module):
             y = _FpnBottleneck.apply(WINOGRAD_TILE, neck._wino_cache, neck.conv.weight, scale, shift, *outs)
         else:
             y = neck(_up_cat(outs, outs[0].shape[2:]))
-        return self.classifier(y)
+        return _classify(self.classifier, y)
 
 
 class UperNetFCNHead(nn.Module):

@@ -221,6 +221,8 @@ def main(argv=None):
     ap.add_argument("--json", type=str, default=None)
     ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--dump_stats", type=str, default=None, help="save the all-reduced packed statistics buffer (rank 0)")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="no MIOpen find-mode benchmarking (its timing-based algorithm choice differs between processes)")
     args = ap.parse_args(argv)
 
     with open(args.cfg) as f:
@@ -244,7 +246,7 @@ def main(argv=None):
     random.seed(SEED)
     np.random.seed(SEED)
     torch.manual_seed(0)  # same random-init weights on every rank
-    torch.backends.cudnn.benchmark = True
+    torch.backends.cudnn.benchmark = not args.deterministic
 
     model = build_model(cfg, random_init=bool(args.synthetic) or args.random_init, device=device)
     for p in model.parameters():

@@ -95,11 +95,13 @@ def main(argv=None):
     ap.add_argument("--bf16", action="store_true")
     ap.add_argument("--json", type=str, default=None)
     ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI)")
+    ap.add_argument("--deterministic", action="store_true", help="no MIOpen find-mode benchmarking")
     ap.add_argument("--emulate_ranks", type=int, default=0,
                     help="single process standing in for N data-parallel ranks: every step runs the N ranks' batches "
                          "one after the other from the same weights and averages their gradients (what DDP's "
                          "all-reduce computes); used to check the multi-rank run")
-    ap.add_argument("--dump_params", type=str, default=None, help="save a few parameter tensors after the last step")
+    ap.add_argument("--dump_params", type=str, default=None,
+                    help="save a sample of parameter tensors and of their (rank-averaged) gradients of the last step")
     args = ap.parse_args(argv)
     with open(args.cfg) as f:
         cfg = yaml.load(f, Loader=yaml.SafeLoader)
@@ -115,7 +117,7 @@ def main(argv=None):
         dist.init_process_group(args.backend, rank=rank, world_size=world)
     dev = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(dev)
-    torch.backends.cudnn.benchmark = True
+    torch.backends.cudnn.benchmark = not args.deterministic
     torch.manual_seed(0)
 
     if model_cfg["NAME"] == "UperNetForSemanticSegmentation":
@@ -212,9 +214,10 @@ def main(argv=None):
         if args.json:
             json.dump(out, open(args.json, "w"))
         if args.dump_params:
-            sd = core.state_dict()
-            keep = [k for k in sd if k.endswith(("gamma", "weight")) and sd[k].dtype == torch.float32][:: max(len(sd) // 24, 1)]
-            torch.save({k: sd[k].detach().cpu() for k in keep}, args.dump_params)
+            named = [(k, p) for k, p in core.named_parameters() if p.grad is not None]
+            keep = named[:: max(len(named) // 24, 1)]
+            torch.save({"params": {k: p.detach().cpu() for k, p in keep}, "grads": {k: p.grad.detach().cpu() for k, p in keep}},
+                       args.dump_params)
     if world > 1:
         dist.destroy_process_group()
 

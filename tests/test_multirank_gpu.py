@@ -49,8 +49,11 @@ def _cfg(tmp_path, name, **train):
 def test_sharded_sea_eval_two_ranks_equal_one_rank(tmp_path):
     from tools import infer
     cfg = _cfg(tmp_path, "pascalvoc_convnext.yaml")
-    common = ["--cfg", cfg, "--eps", "8", "--n_iter", "10", "--synthetic", "6", "--image_size", "64", "--batch_size", "2",
-              "--cleanup", "0"]
+    # 8 images, batches of 2: 4 batches on one rank, 2 + 2 on two (equal batch SIZES: hipBLASLt picks its GEMM kernel
+    # by shape, and a different kernel rounds differently).  512x512: every layer of the model then runs a bitwise reproducible kernel (own kernels + hipBLASLt GEMMs; MIOpen
+    # only serves the stem), and the random starts are per-image streams, so the sharding cannot change a single count
+    common = ["--cfg", cfg, "--eps", "8", "--n_iter", "10", "--synthetic", "8", "--image_size", "512", "--batch_size", "2",
+              "--cleanup", "0", "--deterministic"]
     one = str(tmp_path / "one.pt")
     s1 = infer.main(common + ["--dump_stats", one])
     two, js = str(tmp_path / "two.pt"), str(tmp_path / "two.json")
@@ -58,26 +61,43 @@ def test_sharded_sea_eval_two_ranks_equal_one_rank(tmp_path):
     a, b = torch.load(one), torch.load(two)
     assert a.dtype == torch.int64 and torch.equal(a, b)          # integer tables: independent of the sharding
     s2 = json.load(open(js))
-    assert s2["world"] == 2 and s2["n_images"] == 6
+    assert s2["world"] == 2 and s2["n_images"] == 8
     for k in ("worst_Acc", "final_miou", "loss-wise_miou", "clean"):
         assert s1[k] == s2[k], k
 
 
-def test_ddp_two_ranks_equal_gradient_average_of_one_process(tmp_path):
-    cfg = _cfg(tmp_path, "pascalvoc_convnext.yaml", IMAGE_SIZE=[64, 64], N_ITERS=2)
-    common = ["--cfg", cfg, "--synthetic", "4", "--steps", "2", "--warmup", "0", "--batch_size", "2"]
+@pytest.mark.parametrize("adversarial", [False, True])
+def test_ddp_two_ranks_equal_gradient_average_of_one_process(tmp_path, adversarial):
+    """One PIR-AT outer step (2-step inner PGD + forward/backward) on 2 DDP ranks: the gradients every rank holds after
+    the bucketed all-reduce are the average of the two ranks' gradients, which one process reproduces by running both
+    batches from the same weights and buffers (`--emulate_ranks 2`).  Gradients are compared, not AdamW-updated
+    weights (m / sqrt(v) turns rounding noise of near-zero gradients into +-lr steps)."""
+    # 512x512: the eval-mode inner attack then runs bitwise reproducible kernels only, so both set-ups train on the same
+    # adversarial images; what remains are the atomics of MIOpen's weight-gradient kernels in the outer backward
+    cfg = _cfg(tmp_path, "pascalvoc_convnext.yaml", IMAGE_SIZE=[512, 512], N_ITERS=2, ADVERSARIAL=adversarial)
+    common = ["--cfg", cfg, "--synthetic", "2", "--steps", "1", "--warmup", "0", "--batch_size", "2", "--deterministic"]
     p2, j2 = str(tmp_path / "p2.pt"), str(tmp_path / "j2.json")
     _torchrun(2, ["-m", "tools.train_rob_seg"] + common + ["--backend", "gloo", "--dump_params", p2, "--json", j2])
     from tools import train_rob_seg
     p1, j1 = str(tmp_path / "p1.pt"), str(tmp_path / "j1.json")
     train_rob_seg.main(common + ["--emulate_ranks", "2", "--dump_params", p1, "--json", j1])
-    a, b = torch.load(p1), torch.load(p2)
+    a, b = torch.load(p1)["grads"], torch.load(p2)["grads"]
     assert a.keys() == b.keys() and len(a) >= 8
-    for k in a:
-        torch.testing.assert_close(b[k], a[k], rtol=2e-4, atol=2e-6, msg=k)   # two optimizer steps later
+    rel = {k: ((a[k] - b[k]).norm() / a[k].norm()).item() for k in a if a[k].norm() > 0}
+    assert len(rel) >= 8
+    worst = max(rel, key=rel.get)
+    # Not bitwise: MIOpen's training-mode kernels (weight gradients, BatchNorm) accumulate with atomics and pick
+    # algorithms per process; measured 0.3-0.6 % without and 1-2 % with the sign-step attack in front.  A missing or
+    # wrong all-reduce is an O(1) error (control below).
+    assert rel[worst] <= (5e-2 if adversarial else 1.5e-2), (worst, rel[worst])
+    if not adversarial:   # control: rank 0's own gradient is NOT what the ranks hold after the all-reduce
+        p0 = str(tmp_path / "p0.pt")
+        train_rob_seg.main(common + ["--emulate_ranks", "1", "--dump_params", p0])
+        c = torch.load(p0)["grads"]
+        assert max(((c[k] - b[k]).norm() / b[k].norm()).item() for k in rel) > 0.2
     o1, o2 = json.load(open(j1)), json.load(open(j2))
     assert o2["world"] == 2 and o1["world"] == 1
-    assert o2["last_loss"] == pytest.approx(o1["last_loss"], rel=2e-3)           # rank 0's batch loss of the last step
+    assert o2["last_loss"] == pytest.approx(o1["last_loss"], rel=1e-4)            # rank 0's batch loss
 
 
 def test_bench_starts_its_own_ranks(tmp_path):

@@ -293,6 +293,24 @@ int sea_nhwc_to_nchw(const float* in, const float* scale, const float* residual,
                      int64_t HW, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * M7  fp32 multi-head attention on the matrix cores (v_mfma_f32_32x32x2_f32), flash formulation.
+ *     replaces the explicit softmax(q k^T * scale) v of semseg/models/backbones/vit_encoder.py:106-127 (fp32 operands,
+ *     N = 1025 tokens x 6 heads x 64 in Segmenter ViT-S/16) and its autograd backward.
+ * q, k, v: element (b, h, t, d) at ptr + b*sb + h*sh + t*st + d floats (d contiguous; the three may be slices of one
+ *   packed (B,T,3,H,64) qkv tensor: sb = T*3*H*64, sh = 64, st = 3*H*64).  D must be 64.  Rows 16-byte aligned.
+ * out (B,T,H*64) contiguous: the layout the output projection consumes.  lse (B,H,T): log-sum-exp of the scaled scores.
+ * sea_attention_bwd: grad_out (B,T,H*64) contiguous; delta (B,H,T) scratch; dq/dk/dv are written with strides
+ *   (gsb, gsh, gst) -- pass slices of one (B,T,3,H,64) gradient tensor to get d(qkv) without a concatenation.
+ *   Deterministic (no atomics): S is recomputed in the dq kernel and in the dk/dv kernel.
+ */
+int sea_attention_fwd(const float* q, const float* k, const float* v, int64_t sb, int64_t sh, int64_t st, int B, int H,
+                      int T, int D, float scale, float* out, float* lse, void* stream);
+int sea_attention_bwd(const float* q, const float* k, const float* v, int64_t sb, int64_t sh, int64_t st, int B, int H,
+                      int T, int D, float scale, const float* out, const float* grad_out, const float* lse,
+                      float* delta, float* dq, float* dk, float* dv, int64_t gsb, int64_t gsh, int64_t gst,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Measurement probes (bench.py / tools/kernel_bench.py only; nothing on the product path calls them).
  * sea_probe_stream_copy: dst[0:bytes] = src[0:bytes] with 16-byte-per-lane accesses (non_temporal != 0: nt loads and
  *   stores): the HBM copy ceiling the roofline fractions are also quoted against ("report against a

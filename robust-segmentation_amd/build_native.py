@@ -39,6 +39,7 @@ SOURCES = [
     ("ln_kernels.hip", []),
     ("fpn_fused.hip", []),
     ("probe_kernels.hip", []),
+    ("attention.hip", []),
     ("greedy_host.cpp", ["-ffp-contract=off"]),
     ("api_misc.cpp", []),
 ]

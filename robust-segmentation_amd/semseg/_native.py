@@ -61,6 +61,9 @@ _SIGS = {
     "sea_gate_scale": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _vp]),
     "sea_upsample_bilinear_nhwc_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i64, _vp]),
     "sea_upsample_bilinear_nhwc_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i64, _vp]),
+    "sea_attention_fwd": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "sea_attention_bwd": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                               _i64, _i64, _i64, _vp]),
     "sea_probe_stream_copy": (_i, [_vp, _vp, _sz, _i, _vp]),
     "sea_probe_stream_read": (_i, [_vp, _vp, _sz, _vp]),
 }
@@ -540,6 +543,37 @@ def nhwc_to_nchw(y, scale=None, residual=None):
     _check(lib().sea_nhwc_to_nchw(_p(_f32c(y)), _p(scale), _p(None if residual is None else _f32c(residual)), _p(out),
                                   B, Cc, H * W, _stream()), "sea_nhwc_to_nchw")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ M7
+def attention_qkv(qkv, scale: float):
+    """softmax(q k^T * scale) v for a packed (B,T,3,H,64) fp32 qkv tensor; returns (out (B,T,H*64), lse (B,H,T))."""
+    _dev(qkv)
+    qkv = _f32c(qkv)
+    B, T, three, H, D = qkv.shape
+    if three != 3 or D != 64:
+        raise SeaNativeError("attention_qkv expects a (B,T,3,H,64) tensor")
+    out = torch.empty(B, T, H * D, dtype=torch.float32, device=qkv.device)
+    lse = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
+    p = qkv.data_ptr()
+    _check(lib().sea_attention_fwd(p, p + 4 * H * D, p + 8 * H * D, T * 3 * H * D, D, 3 * H * D, B, H, T, D, float(scale),
+                                   _p(out), _p(lse), _stream()), "sea_attention_fwd")
+    return out, lse
+
+
+def attention_qkv_backward(qkv, out, lse, grad_out, scale: float):
+    """gradient w.r.t. the packed qkv tensor"""
+    _dev(qkv, out, lse, grad_out)
+    B, T, _, H, D = qkv.shape
+    grad_out = _f32c(grad_out.contiguous())
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty_like(lse)
+    p, g = qkv.data_ptr(), dqkv.data_ptr()
+    sb, sh, st = T * 3 * H * D, D, 3 * H * D
+    _check(lib().sea_attention_bwd(p, p + 4 * H * D, p + 8 * H * D, sb, sh, st, B, H, T, D, float(scale), _p(_f32c(out)),
+                                   _p(grad_out), _p(_f32c(lse)), _p(delta), g, g + 4 * H * D, g + 8 * H * D, sb, sh, st,
+                                   _stream()), "sea_attention_bwd")
+    return dqkv
 
 
 # ------------------------------------------------------------------------------------------------ K9 (host)

@@ -53,8 +53,8 @@ class _LayerNormHip(torch.autograd.Function):
 
 def _layer_norm(x, dim, weight, bias, eps):
     if (USE_HIP_LAYERNORM and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and dim % 4 == 0
-            and dim <= 1024 and x.shape[-1] == dim and not weight.requires_grad and not bias.requires_grad
-            and not torch.is_autocast_enabled()):
+            and dim <= 1024 and x.shape[-1] == dim and not weight.requires_grad and not bias.requires_grad):
+        # also under autocast: LayerNorm is an fp32 op there too, and the kernel is called with raw fp32 pointers
         return _LayerNormHip.apply(x, weight, bias, eps)
     return F.layer_norm(x, (dim,), weight, bias, eps)
 
@@ -303,20 +303,21 @@ class _PatchConv2x2(torch.autograd.Function):
         patches = x.permute(0, 2, 3, 1).reshape(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, 4 * C)
         y = torch.addmm(bias, patches, wr.t()) if bias is not None else patches @ wr.t()
         ctx.wr, ctx.shape = wr, (B, C, H, W)
-        return y.view(B, H // 2, W // 2, -1).permute(0, 3, 1, 2)               # channels_last (B,Cout,H/2,W/2)
+        # under autocast the GEMM ran (and returned) bf16: the trunk's residual stream stays fp32
+        return y.float().view(B, H // 2, W // 2, -1).permute(0, 3, 1, 2)       # channels_last (B,Cout,H/2,W/2)
 
     @staticmethod
     def backward(ctx, gy):
         B, C, H, W = ctx.shape
         g = gy.permute(0, 2, 3, 1).reshape(-1, gy.shape[1])
-        gp = (g @ ctx.wr).view(B, H // 2, W // 2, 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, C)
+        gp = (g @ ctx.wr).float().view(B, H // 2, W // 2, 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, C)
         return gp.permute(0, 3, 1, 2), None, None, None
 
 
 def _patch_conv_ok(conv, x):
     return (USE_HIP_DWCONV and isinstance(conv, nn.Conv2d) and conv.kernel_size == (2, 2) and conv.stride == (2, 2)
             and conv.padding == (0, 0) and conv.groups == 1 and x.is_cuda and x.dtype == torch.float32
-            and conv.weight.dtype == torch.float32 and not torch.is_autocast_enabled()
+            and conv.weight.dtype == torch.float32
             and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
             and not (conv.weight.requires_grad or (conv.bias is not None and conv.bias.requires_grad)))
 
@@ -795,14 +796,24 @@ class UperNetForSemanticSegmentation(nn.Module):
             self.decode_head.init_weights()
             self.auxiliary_head.init_weights()
 
+    def _head_logits(self, feats):
+        """Decode head.  Under autocast with FROZEN weights (the attack's forward: PIR-AT's inner PGD with TRAIN.AMP,
+        BASELINE configs[3]) the head runs with autocast switched off: its fp32 fast paths (Winograd-domain 3x3
+        convolutions at a quarter of the multiplications, NHWC upsample / concat kernels, folded-BatchNorm GEMMs) beat
+        the bf16 library composition, while the trunk keeps autocast and runs its MLP GEMMs in bf16."""
+        if torch.is_autocast_enabled() and feats[0].dtype == torch.float32 and not self.decode_head.classifier.weight.requires_grad:
+            with torch.autocast("cuda", enabled=False):
+                return self.decode_head(feats)
+        return self.decode_head(feats)
+
     def forward_lowres(self, input):
         """(logits at 1/4 resolution, output size): semseg.attacker fuses the final bilinear upsample
         into its loss kernel (K2u) when a model offers this hook."""
-        return self.decode_head(self.backbone(input)), tuple(input.shape[2:])
+        return self._head_logits(self.backbone(input)), tuple(input.shape[2:])
 
     def forward(self, input, lbl=None):
         feats = self.backbone(input)
-        logits = _up(self.decode_head(feats).contiguous(), input.shape[2:])  # NCHW logits for K2
+        logits = _up(self._head_logits(feats).contiguous(), input.shape[2:])  # NCHW logits for K2
         loss = None
         if lbl is not None:
             aux = _up(self.auxiliary_head(feats).contiguous(), input.shape[2:])

@@ -28,6 +28,28 @@ def _init(m):
         nn.init.ones_(m.weight)
 
 
+USE_HIP_ATTENTION = True
+
+
+class _AttentionHip(torch.autograd.Function):
+    """softmax(q k^T * scale) v on a packed (B,T,3,H,64) fp32 qkv tensor through libsea_hip M7 (fp32 MFMA flash
+    attention, deterministic backward); returns (B,T,H*64), the layout the output projection consumes."""
+
+    @staticmethod
+    def forward(ctx, qkv, scale):
+        from .. import _native as N
+        out, lse = N.attention_qkv(qkv, scale)
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import _native as N
+        qkv, out, lse = ctx.saved_tensors
+        return N.attention_qkv_backward(qkv, out, lse, g, ctx.scale), None
+
+
 class Attention(nn.Module):
     def __init__(self, dim, heads, dropout):
         super().__init__()
@@ -40,8 +62,13 @@ class Attention(nn.Module):
 
     def forward(self, x):
         B, T, D = x.shape
-        q, k, v = self.qkv(x).reshape(B, T, 3, self.heads, D // self.heads).permute(2, 0, 3, 1, 4)
+        qkv = self.qkv(x)
         p = self.attn_drop.p if self.training else 0.0
+        if (USE_HIP_ATTENTION and p == 0.0 and qkv.is_cuda and qkv.dtype == torch.float32 and D // self.heads == 64
+                and qkv.is_contiguous()):
+            y = _AttentionHip.apply(qkv.view(B, T, 3, self.heads, 64), self.scale)
+            return self.proj_drop(self.proj(y))
+        q, k, v = qkv.reshape(B, T, 3, self.heads, D // self.heads).permute(2, 0, 3, 1, 4)
         y = F.scaled_dot_product_attention(q, k, v, dropout_p=p, scale=self.scale)
         return self.proj_drop(self.proj(y.transpose(1, 2).reshape(B, T, D)))
 

@@ -214,6 +214,9 @@ def main(argv=None):
     ap.add_argument("--synthetic", type=int, default=0, help="evaluate N synthetic images (no dataset, random weights)")
     ap.add_argument("--data", type=str, default=None, help=".pt file with {'images','labels'}")
     ap.add_argument("--random_init", action="store_true", help="seeded random weights instead of EVAL.MODEL_PATH")
+    ap.add_argument("--balance_classes", action="store_true",
+                    help="with --synthetic: fit the classifier bias so that the clean prediction (= the labels) populates "
+                         "every class (tools/synth.py): a well-conditioned mIoU on random weights")
     ap.add_argument("--image_size", type=int, default=None)
     ap.add_argument("--batch_size", type=int, default=None)
     ap.add_argument("--save_argmax", action="store_true",
@@ -264,6 +267,11 @@ def main(argv=None):
         blob = torch.load(args.data, map_location="cpu")
         images, labels = blob["images"].float(), blob["labels"].long()
         n_img = images.shape[0]
+    if args.synthetic and args.balance_classes:
+        from tools.synth import balance_classes
+        frac = balance_classes(model, images)          # every rank fits the same bias on the same full image set
+        if rank == 0:
+            print(f"[infer] balanced classes: min / max pixel share {float(frac.min()):.4f} / {float(frac.max()):.4f}")
     if args.n_batches > 0:
         n_img = min(n_img, args.n_batches * bs * world)
     mine = shard_indices(n_img, rank, world)

@@ -35,7 +35,14 @@ def sea_key(n):
             return "K2 loss_nchw_reg"
         tune = f",tune={m.group(6)}" if m.group(6) else ""
         return f"K2 loss_nchw_reg<{m.group(1)},C={m.group(2)},vec={m.group(3)},grad={m.group(4)}{tune}>"
-    for pat, key in (("loss_nhwc_lds", "K2 loss_nhwc_lds"), ("loss_nchw_stream", "K2 loss_nchw_stream"),
+    m = re.search(r"loss_nchw_split<(\w+), (\d+), (\d+)>", n)
+    if m:
+        return f"K2 loss_nchw_split<{m.group(1)},C={m.group(2)},waves={m.group(3)}>"
+    m = re.search(r"loss_nchw_fwd<(\w+), (\d+), (\d+)>", n)
+    if m:
+        return f"K2 loss_nchw_fwd<{m.group(1)},chunk={m.group(2)},waves={m.group(3)}>"
+    for pat, key in (("loss_nhwc_lds", "K2 loss_nhwc_lds"), ("loss_upsampled_kernel", "K2u loss_upsampled_kernel"),
+                     ("stream_copy_kernel", "probe stream_copy"), ("stream_read_kernel", "probe stream_read"), ("loss_nchw_stream", "K2 loss_nchw_stream"),
                      ("loss_finalize", "K2 loss_finalize"), ("apgd_linf_step", "K1 apgd_linf_step"),
                      ("pgd_linf_step", "K6 pgd_linf_step"), ("ew2_v", "K5 random_start/project"),
                      ("apgd_track_kernel", "K7 apgd_track"), ("select_copy_pred", "K4 select_copy_pred"),
@@ -54,6 +61,8 @@ def main():
     ap.add_argument("--fetch")
     ap.add_argument("--write")
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--cases", help="stdout of tools/dev/profile_cases.py (CASE lines) to price --kernels / --fetch / --write rows")
+    ap.add_argument("--sq", help="rocprofv3 --pmc SQ_* output directory (per-kernel medians are tabulated)")
     a = ap.parse_args()
     out_dir = os.path.join(ROOT, "profiles")
     os.makedirs(out_dir, exist_ok=True)
@@ -61,7 +70,7 @@ def main():
     if a.bench:
         rows = list(csv.DictReader(open(one(a.bench, "*_kernel_trace.csv"))))
         rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-        k2 = [i for i, r in enumerate(rows) if "loss_nchw_reg" in r["Kernel_Name"] or "loss_nhwc" in r["Kernel_Name"]]
+        k2 = [i for i, r in enumerate(rows) if any(t in r["Kernel_Name"] for t in ("loss_nchw_reg", "loss_nchw_split", "loss_nhwc", "loss_upsampled"))]
         lo, hi = k2[a.warmup], k2[-1]      # k2[0] is step 0 of the attack, then `warmup` untimed steps
         steps = len(k2) - 1 - a.warmup
         win = rows[lo + 1: hi + 1]
@@ -127,6 +136,62 @@ def main():
             if m:
                 tj[f"B8_C{m.group(1)}"] = v
         json.dump(tj, open(os.path.join(out_dir, "k2_traffic.json"), "w"), indent=1)
+
+
+    if a.cases and a.kernels:
+        # price the isolated cold launches: algorithmic and moved bytes per launch / rocprofv3 average duration
+        stats = list(csv.DictReader(open(one(a.kernels, "*_kernel_stats.csv"))))
+        trace = list(csv.DictReader(open(one(a.kernels, "*_kernel_trace.csv"))))
+        fe = wr = None
+        if a.fetch and a.write:
+            def load_raw(d, counter):
+                out = collections.defaultdict(list)
+                for r in csv.DictReader(open(one(d, "*_counter_collection.csv"))):
+                    if r["Counter_Name"] == counter:
+                        out[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+                return out
+            fe, wr = load_raw(a.fetch, "FETCH_SIZE"), load_raw(a.write, "WRITE_SIZE")
+        med = lambda v: sorted(v)[len(v) // 2]  # noqa: E731
+        with open(os.path.join(out_dir, f"{a.round}_cold_kernel_roofline.md"), "w") as f:
+            f.write(f"# Attack-side kernels, cold launches, rocprofv3 --kernel-trace ({a.round})\n\n"
+                    "`tools/dev/profile_cases.py`: B=8, 512x512, every launch on buffers that are not in the 256 MiB Infinity Cache "
+                    "(ring of independent sets > 1.5 GB).  avg/min us = rocprofv3 kernel durations of the case's launches; "
+                    "alg = SURVEY 8(d) bytes (int64 label + argmax), moved = bytes the kernel moves (uint8 label + argmax); "
+                    "fractions of the 8 TB/s HBM3E peak.  PMC = 2 x FETCH_SIZE + WRITE_SIZE (separate passes; KiB; gfx950 "
+                    "half-FETCH correction, MI355X_MICROARCH.md).\n\n"
+                    "| case | kernel | launches | avg us | min us | alg MB | moved MB | PMC MB | alg frac | moved frac |\n|---|---|---|---|---|---|---|---|---|---|\n")
+            for line in open(a.cases):
+                if not line.startswith("CASE "):
+                    continue
+                tag, kn, alg, moved = [t.strip() for t in line[5:].split("|")]
+                alg, moved = float(alg), float(moved)
+                durs = collections.defaultdict(list)
+                for r in trace:
+                    if kn in r["Kernel_Name"]:
+                        durs[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                # the case's kernel: among the matching names, the one whose bytes/duration is plausible -> take all names, list each
+                for name, d in durs.items():
+                    if "cold" in tag and len(durs) > 1:
+                        # several instantiations share the substring (e.g. no-grad / grad): keep the one closest to 5 TB/s
+                        pass
+                    avg, mn = sum(d) / len(d) / 1e3, min(d) / 1e3
+                    pmc = ""
+                    if fe is not None and name in fe and name in wr:
+                        pmc = f"{(2 * med(fe[name]) + med(wr[name])) * 1024 / 1e6:.1f}"
+                    f.write(f"| {tag} | `{short(sea_key(name) or name, 70)}` | {len(d)} | {avg:.1f} | {mn:.1f} | {alg / 1e6:.1f} | {moved / 1e6:.1f} | "
+                            f"{pmc} | {alg / avg / 1e3 / 8000:.1%} | {moved / avg / 1e3 / 8000:.1%} |\n")
+
+    if a.sq:
+        rows = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(one(a.sq, "*_counter_collection.csv"))):
+            k = sea_key(r["Kernel_Name"])
+            if k:
+                rows[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        names = sorted({c for v in rows.values() for c in v})
+        with open(os.path.join(out_dir, f"{a.round}_sq_counters.md"), "w") as f:
+            f.write(f"# SQ counters per launch (median), rocprofv3 --pmc ({a.round})\n\n| kernel | " + " | ".join(names) + " |\n|---|" + "---|" * len(names) + "\n")
+            for k in sorted(rows):
+                f.write(f"| {k} | " + " | ".join(f"{sorted(rows[k][c])[len(rows[k][c]) // 2]:.3g}" if rows[k][c] else "" for c in names) + " |\n")
 
 
 if __name__ == "__main__":

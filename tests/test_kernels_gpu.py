@@ -951,3 +951,57 @@ def test_counts_full_size_ade(N):
             assert torch.equal(a.cpu(), b)
     hist = N.confusion(pred.cuda(), y.cuda(), C)
     assert torch.equal(hist.cpu(), O.confusion_matrix(pred, y, C))
+
+
+# ------------------------------------------------------------------------------------------------ M7 attention
+@pytest.mark.parametrize("case", [(2, 6, 1025, "ViT-S/16 encoder, 512x512"), (1, 6, 1175, "mask transformer, 1024 patches + 151 classes"),
+                                  (3, 2, 64, "one tile"), (1, 1, 33, "ragged"), (2, 3, 130, "two blocks, ragged")])
+def test_fp32_mfma_attention_forward_and_backward(N, case):
+    """softmax(q k^T * scale) v as written in the reference (vit_encoder.py:106-127), explicit fp32 (and an fp64 check)."""
+    B, H, T, _ = case
+    g = torch.Generator().manual_seed(T)
+    qkv = torch.randn(B, T, 3, H, 64, generator=g)
+    qkv[:, :, 0] *= 1.5                                      # asymmetric operands: a transposed tile would not cancel
+    qkv[:, 3 % T, 1] += 2.0                                  # one key that dominates some rows (large max)
+    gout = torch.randn(B, T, H * 64, generator=g)
+    scale = 64 ** -0.5
+
+    def ref(t, dt):
+        x = t.to(dt).requires_grad_(True)
+        q, k, v = x.permute(2, 0, 3, 1, 4)
+        att = ((q @ k.transpose(-2, -1)) * scale).softmax(-1)
+        y = (att @ v).transpose(1, 2).reshape(B, T, H * 64)
+        (gx,) = torch.autograd.grad(y, [x], grad_outputs=gout.to(dt))
+        return y.detach(), gx
+
+    y64, g64 = ref(qkv, torch.float64)
+    out, lse = N.attention_qkv(dev(qkv), scale)
+    dq = N.attention_qkv_backward(dev(qkv), out, lse, dev(gout), scale)
+    torch.cuda.synchronize()
+    err_y = (out.cpu().double() - y64).abs().max().item()
+    err_g = (dq.cpu().double() - g64).abs().max().item()
+    y32, g32 = ref(qkv, torch.float32)                        # the fp32 composition's own error vs fp64 as yardstick
+    assert err_y <= max(2e-6, 3 * (y32.double() - y64).abs().max().item()), err_y
+    assert err_g <= max(1e-5, 3 * (g32.double() - g64).abs().max().item()), err_g
+    ref_lse = torch.logsumexp((qkv[:, :, 0].permute(0, 2, 1, 3).double() @ qkv[:, :, 1].permute(0, 2, 3, 1).double()) * scale, -1)
+    torch.testing.assert_close(lse.cpu().double(), ref_lse, rtol=1e-6, atol=1e-5)
+    # deterministic
+    dq2 = N.attention_qkv_backward(dev(qkv), out, lse, dev(gout), scale)
+    assert torch.equal(dq, dq2)
+
+
+def test_segmenter_uses_hip_attention_and_matches_sdpa(N):
+    from semseg.models import segmenter as S
+    torch.manual_seed(0)
+    att = S.Attention(384, 6, 0.0).cuda().eval()
+    x = torch.randn(2, 1025, 384, device="cuda", requires_grad=True)
+    gy = torch.randn(2, 1025, 384, device="cuda")
+    outs = []
+    for flag in (True, False):
+        S.USE_HIP_ATTENTION = flag
+        y = att(x)
+        (gx,) = torch.autograd.grad(y, [x], grad_outputs=gy)
+        outs.append((y.detach(), gx))
+    S.USE_HIP_ATTENTION = True
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-4, atol=2e-5)

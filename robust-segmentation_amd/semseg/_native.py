@@ -505,7 +505,8 @@ def wino_conv3x3_cl(x, U, m: int, bias=None, scale=None, relu: bool = False, gat
         _check(L.sea_wino_input_transform(_p(t), xps, _p(gate), _p(gate_scale), V.data_ptr() + 4 * off, Cin, B, t.shape[1],
                                           H, W, m, _stream()), "sea_wino_input_transform")
         off += t.shape[1]
-    Mx = torch.bmm(V, U)  # (A*A) independent fp32 GEMMs: hipBLASLt strided-batched
+    with torch.autocast("cuda", enabled=False):
+        Mx = _f32c(torch.bmm(V, U))  # (A*A) independent fp32 GEMMs: hipBLASLt strided-batched
     del V
     y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=xs[0].device, memory_format=torch.channels_last)
     if addend is not None and (tuple(addend.shape) != (B, Cout, H, W) or cl_pixel_stride(addend) != Cout):

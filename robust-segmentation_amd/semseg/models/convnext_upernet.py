@@ -31,6 +31,12 @@ CONVNEXT_SETTINGS = {
 }
 
 
+# The custom autograd Functions below hand raw fp32 pointers to libsea_hip and call torch GEMMs in between.  Under
+# autocast (PIR-AT's inner PGD with TRAIN.AMP) they are fp32 islands: inputs are cast to fp32 and autocast is off
+# inside forward AND backward (a bf16 torch.bmm result handed to an fp32 kernel reads past its buffer).
+_fp32_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_fp32_bwd = torch.amp.custom_bwd(device_type="cuda")
+
 USE_HIP_LAYERNORM = True
 
 
@@ -38,6 +44,7 @@ class _LayerNormHip(torch.autograd.Function):
     """LayerNorm over the last dim through libsea_hip M5 (frozen affine parameters: input gradient only)."""
 
     @staticmethod
+    @_fp32_fwd
     def forward(ctx, x, weight, bias, eps):
         from .. import _native as N
         y, mean, rstd = N.layernorm(x, weight, bias, eps)
@@ -45,6 +52,7 @@ class _LayerNormHip(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_fp32_bwd
     def backward(ctx, g):
         from .. import _native as N
         x, weight, mean, rstd = ctx.saved_tensors
@@ -97,6 +105,7 @@ class _DwConv7x7(torch.autograd.Function):
     input gradient.  The weight/bias gradients (only needed when training) use PyTorch."""
 
     @staticmethod
+    @_fp32_fwd
     def forward(ctx, x, weight, bias):
         from .. import _native as N
         ctx.save_for_backward(x, weight)
@@ -104,6 +113,7 @@ class _DwConv7x7(torch.autograd.Function):
         return N.dwconv7x7(x.contiguous(), weight.contiguous(), bias, flip=False)
 
     @staticmethod
+    @_fp32_bwd
     def backward(ctx, gy):
         from .. import _native as N
         x, weight = ctx.saved_tensors
@@ -123,6 +133,7 @@ class _DwConv7x7NHWC(torch.autograd.Function):
     layout any more."""
 
     @staticmethod
+    @_fp32_fwd
     def forward(ctx, x, weight, bias, wt):
         from .. import _native as N
         ctx.save_for_backward(x, weight, wt)
@@ -130,6 +141,7 @@ class _DwConv7x7NHWC(torch.autograd.Function):
         return N.dwconv7x7_nhwc(x, wt, bias, flip=False)
 
     @staticmethod
+    @_fp32_bwd
     def backward(ctx, gy):
         from .. import _native as N
         x, weight, wt = ctx.saved_tensors
@@ -182,11 +194,13 @@ class _ToNHWC(torch.autograd.Function):
     opposite transpose."""
 
     @staticmethod
+    @_fp32_fwd
     def forward(ctx, x):
         from .. import _native as N
         return N.nchw_to_nhwc(x)
 
     @staticmethod
+    @_fp32_bwd
     def backward(ctx, g):
         from .. import _native as N
         return N.nhwc_to_nchw(g.contiguous())
@@ -197,12 +211,14 @@ class _ScaleResidual(torch.autograd.Function):
     block in one pass; backward sends gamma[c] * g^T to the branch and g unchanged to the trunk."""
 
     @staticmethod
+    @_fp32_fwd
     def forward(ctx, x, y, gamma):
         from .. import _native as N
         ctx.save_for_backward(y if (gamma is not None and gamma.requires_grad) else None, gamma)
         return N.nhwc_to_nchw(y, gamma, x)
 
     @staticmethod
+    @_fp32_bwd
     def backward(ctx, g):
         from .. import _native as N
         y, gamma = ctx.saved_tensors
@@ -390,6 +406,7 @@ class _WinoConv3x3(torch.autograd.Function):
     in the output transform, and their backward in the input transform of the gradient convolution."""
 
     @staticmethod
+    @_fp32_fwd
     def forward(ctx, x, weight, m, cache, scale, shift, relu):
         from .. import _native as N
         key = (_tkey(weight), m)
@@ -402,6 +419,7 @@ class _WinoConv3x3(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_fp32_bwd
     def backward(ctx, gy):
         from .. import _native as N
         cache = ctx.cache
@@ -501,6 +519,7 @@ class _UpsampleBilinear(torch.autograd.Function):
     NHWC kernels run lanes along C, so no layout copy surrounds the op."""
 
     @staticmethod
+    @_fp32_fwd
     def forward(ctx, x, size):
         from .. import _native as N
         ctx.in_size = tuple(x.shape[2:])
@@ -510,6 +529,7 @@ class _UpsampleBilinear(torch.autograd.Function):
         return N.upsample_bilinear(x.contiguous(), size)
 
     @staticmethod
+    @_fp32_bwd
     def backward(ctx, gy):
         from .. import _native as N
         if ctx.cl:
@@ -541,12 +561,14 @@ class _UpAddCL(torch.autograd.Function):
     """res + up(x) in one pass over channels_last tensors (the FPN top-down add)."""
 
     @staticmethod
+    @_fp32_fwd
     def forward(ctx, x, res):
         from .. import _native as N
         ctx.in_size = tuple(x.shape[2:])
         return N.upsample_bilinear_cl(_dense_cl(x), res.shape[2:], residual=_dense_cl(res))
 
     @staticmethod
+    @_fp32_bwd
     def backward(ctx, gy):
         from .. import _native as N
         g = gy if N.cl_pixel_stride(gy) is not None else gy.contiguous(memory_format=_CL)
@@ -560,6 +582,7 @@ class _UpCatCL(torch.autograd.Function):
     gathers each gradient straight out of the matching slice of the buffer's gradient."""
 
     @staticmethod
+    @_fp32_fwd
     def forward(ctx, size, *ts):
         from .. import _native as N
         B, (H, W) = ts[0].shape[0], size
@@ -577,6 +600,7 @@ class _UpCatCL(torch.autograd.Function):
         return buf
 
     @staticmethod
+    @_fp32_bwd
     def backward(ctx, g):
         from .. import _native as N
         if N.cl_pixel_stride(g) != g.shape[1]:
@@ -629,6 +653,7 @@ class _FpnBottleneck(torch.autograd.Function):
     """relu(bn(conv3x3(cat([f0, up(f1), ..., up(fn)])))) for frozen weights / eval-mode BatchNorm, input grads only."""
 
     @staticmethod
+    @_fp32_fwd
     def forward(ctx, m, cache, weight, scale, shift, *fs):
         from .. import _native as N
         B, (H, W), Cout = fs[0].shape[0], fs[0].shape[2:], weight.shape[0]
@@ -657,6 +682,7 @@ class _FpnBottleneck(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_fp32_bwd
     def backward(ctx, gy):
         from .. import _native as N
         y, scale = ctx.saved_tensors

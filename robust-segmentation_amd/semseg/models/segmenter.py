@@ -36,6 +36,7 @@ class _AttentionHip(torch.autograd.Function):
     attention, deterministic backward); returns (B,T,H*64), the layout the output projection consumes."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, qkv, scale):
         from .. import _native as N
         out, lse = N.attention_qkv(qkv, scale)
@@ -44,6 +45,7 @@ class _AttentionHip(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g):
         from .. import _native as N
         qkv, out, lse = ctx.saved_tensors

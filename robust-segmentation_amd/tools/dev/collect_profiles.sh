@@ -1,0 +1,24 @@
+#!/bin/bash
+# Collect the round's rocprofv3 evidence on the GPU box (raw output in /tmp, summaries into gpurun_out/ -> profiles/).
+#   gpurun -- 'bash robust-segmentation_amd/tools/dev/collect_profiles.sh r2'
+R=${1:-r2}
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out
+RAW=/tmp/sea_prof_$R
+mkdir -p $OUT $RAW
+export TMPDIR=/tmp
+cd $REPO
+CASES=robust-segmentation_amd/tools/dev/profile_cases.py
+python3 $CASES > $OUT/${R}_cases.txt 2>$RAW/cases.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/cases -- python3 $CASES > $RAW/cases_kt.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $RAW/fetch -- python3 $CASES > $RAW/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $RAW/write -- python3 $CASES > $RAW/write.log 2>&1
+SEA_PROFILE_REPS=2 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES \
+  --output-format csv -d $RAW/sq -- python3 $CASES > $RAW/sq.log 2>&1 || tail -3 $RAW/sq.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/bench -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/${R}_prof_bench.log 2>&1
+SQ=""
+ls $RAW/sq/*/*_counter_collection.csv >/dev/null 2>&1 && SQ="--sq $RAW/sq"
+python3 robust-segmentation_amd/tools/summarize_profile.py --round $R --bench $RAW/bench --kernels $RAW/cases --fetch $RAW/fetch \
+  --write $RAW/write --cases $OUT/${R}_cases.txt $SQ 2>&1 | tail -5
+cp profiles/${R}_* profiles/k2_traffic.json $OUT/ 2>/dev/null
+ls -la $OUT | tail -12

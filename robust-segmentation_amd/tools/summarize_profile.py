@@ -132,8 +132,8 @@ def main():
                 traffic[k] = (rd + wt) * 1e6
         tj = {}
         for k, v in traffic.items():
-            m = re.search(r"K2 loss_nchw_reg<float,C=(\d+),", k)
-            if m:
+            m = re.search(r"K2 loss_nchw_(?:reg|split)<float,C=(\d+),", k)
+            if m and "grad=false" not in k:
                 tj[f"B8_C{m.group(1)}"] = v
         json.dump(tj, open(os.path.join(out_dir, "k2_traffic.json"), "w"), indent=1)
 

@@ -123,6 +123,6 @@ def test_pirat_inner_pgd_convnext_s_fp32_and_bf16(ctx):
     with torch.no_grad():
         ce_b = torch.nn.functional.cross_entropy(model(xb), y).item()
     print("pgd gain fp32 / bf16 / reference:", ce - ce0, ce_b - ce0, ref_gain)
-    assert ce_b - ce0 >= 0.8 * ref_gain, (ce_b - ce0, ref_gain)
+    assert ce_b - ce0 == pytest.approx(ref_gain, rel=0.05), (ce_b - ce0, ref_gain)   # measured: 0.033689 vs 0.033708
     gotb = xb.flatten()[g["idx"].cuda()].cpu()
     assert ((gotb - g["pgd_x_adv_samples"]).abs() > 1e-6).float().mean().item() <= 0.35

@@ -34,6 +34,9 @@ constexpr float kLn2 = 0.6931471805599453f;
 
 __device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
+// v_exp_f32 itself (2^x, flushes results below 2^-126 to zero: irrelevant next to a soft-max sum >= 1)
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 __device__ __forceinline__ f32x16 zero16() {
   f32x16 z;
 #pragma unroll
@@ -137,6 +140,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnPtrs p, int T, int
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
   const int q_row = blockIdx.x * 128 + wave * 32 + (lane & 31);
   const bool q_ok = q_row < T;
+  const bool wave_rows = blockIdx.x * 128 + wave * 32 < T;  // wave-uniform
   const float* qb = p.q + (int64_t)b * p.sb + (int64_t)h * p.sh;
   const float* kb = p.k + (int64_t)b * p.sb + (int64_t)h * p.sh;
   const float* vb = p.v + (int64_t)b * p.sb + (int64_t)h * p.sh;
@@ -160,6 +164,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnPtrs p, int T, int
       load_tile_regs(kb, p.st, (j + 1) * kTile, T, kr);
       load_tile_regs(vb, p.st, (j + 1) * kTile, T, vr);
     }
+    if (!wave_rows) continue;  // this wave's 32 rows lie beyond T: it only helps staging the tiles
     // S^T (keys on the registers, query on the lane), two 32-key sub-blocks
     f32x16 s0 = tile_times_regs(ks, 0, lane, qreg, zero16());
     f32x16 s1 = tile_times_regs(ks, 1, lane, qreg, zero16());
@@ -178,12 +183,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnPtrs p, int T, int
     for (int t = 0; t < 16; ++t) m_t = fmaxf(m_t, s1[t]);
     m_t = fmaxf(m_t, __shfl_xor(m_t, 32, 64));
     const float m_new = fmaxf(m_run, m_t);  // finite: every tile holds at least one existing key
-    const float alpha = exp2f(m_run - m_new);
+    const float alpha = fast_exp2(m_run - m_new);
     float psum = 0.f;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
-      s0[t] = exp2f(s0[t] - m_new);
-      s1[t] = exp2f(s1[t] - m_new);
+      s0[t] = fast_exp2(s0[t] - m_new);
+      s1[t] = fast_exp2(s1[t] - m_new);
       psum += s0[t] + s1[t];
     }
     l_run = l_run * alpha + psum;
@@ -260,6 +265,7 @@ __global__ __launch_bounds__(256, 2) void attn_dq_kernel(AttnPtrs p, int T, int 
       load_tile_regs(kb, p.st, (j + 1) * kTile, T, kr);
       load_tile_regs(vb, p.st, (j + 1) * kTile, T, vr);
     }
+    if (blockIdx.x * 128 + wave * 32 >= T) continue;  // wave-uniform: rows beyond T, the wave only stages tiles
     const int key0 = j * kTile;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
@@ -268,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void attn_dq_kernel(AttnPtrs p, int T, int 
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         const bool exists = key0 + 32 * rb + acc_row(t, half) < T;
-        const float pr = exists ? exp2f(s[t] - lse2) : 0.f;
+        const float pr = exists ? fast_exp2(s[t] - lse2) : 0.f;
         s[t] = pr * (dp[t] - dlt) * scale;                         // dS^T
       }
       dq0 = tile_t_times_acc(ks, rb, 0, lane, s, dq0);             // dQ^T += K^T dS^T
@@ -320,6 +326,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(AttnPtrs p, int T, int
       load_tile_regs(qb, p.st, (j + 1) * kTile, T, qr);
       load_tile_regs(gb, gst_o, (j + 1) * kTile, T, gr);
     }
+    if (blockIdx.x * 128 + wave * 32 >= T) continue;  // wave-uniform: key rows beyond T
     const int q0 = j * kTile;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
@@ -330,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(AttnPtrs p, int T, int
       for (int t = 0; t < 16; ++t) {
         const int ql = 32 * rb + acc_row(t, half);
         const bool exists = (q0 + ql < T) && k_ok;
-        pr[t] = exists ? exp2f(s[t] - lse_s[ql]) : 0.f;
+        pr[t] = exists ? fast_exp2(s[t] - lse_s[ql]) : 0.f;
         s[t] = pr[t] * (dp[t] - dlt_s[ql]) * scale;                 // dS
       }
       dv0 = tile_t_times_acc(gs, rb, 0, lane, pr, dv0);            // dV^T += dO^T P

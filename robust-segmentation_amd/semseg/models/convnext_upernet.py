@@ -32,10 +32,31 @@ CONVNEXT_SETTINGS = {
 
 
 # The custom autograd Functions below hand raw fp32 pointers to libsea_hip and call torch GEMMs in between.  Under
-# autocast (PIR-AT's inner PGD with TRAIN.AMP) they are fp32 islands: inputs are cast to fp32 and autocast is off
-# inside forward AND backward (a bf16 torch.bmm result handed to an fp32 kernel reads past its buffer).
-_fp32_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-_fp32_bwd = torch.amp.custom_bwd(device_type="cuda")
+# autocast (PIR-AT's inner PGD with TRAIN.AMP) they are fp32 islands: floating-point inputs are cast to fp32 and
+# autocast is off inside forward AND backward (a bf16 torch.bmm result handed to an fp32 kernel reads past its buffer).
+# Same contract as torch.amp.custom_fwd(cast_inputs=torch.float32) / custom_bwd, without their per-call context
+# managers when autocast is off (about 200 Function calls per attack step: ~1.5 ms of host time per step, which made
+# ConvNeXt-S launch-bound).
+def _fp32_fwd(fn):
+    def forward(ctx, *args):
+        if torch.is_autocast_enabled():
+            args = [a.float() if (torch.is_tensor(a) and a.is_floating_point() and a.dtype != torch.float32) else a
+                    for a in args]
+            with torch.autocast("cuda", enabled=False):
+                return fn(ctx, *args)
+        return fn(ctx, *args)
+    return forward
+
+
+def _fp32_bwd(fn):
+    def backward(ctx, *grads):
+        if torch.is_autocast_enabled():
+            grads = [g.float() if (torch.is_tensor(g) and g.dtype != torch.float32) else g for g in grads]
+            with torch.autocast("cuda", enabled=False):
+                return fn(ctx, *grads)
+        return fn(ctx, *grads)
+    return backward
+
 
 USE_HIP_LAYERNORM = True
 
@@ -162,7 +183,7 @@ def _tkey(*ts):
     device of every source.  The identity term covers a parameter that was REPLACED by a fresh tensor which happens
     to reuse a freed address at version 0 (``module.weight = nn.Parameter(...)``, a re-materialised model), and the
     caches copied along by ``copy.deepcopy`` (new parameter objects -> new key); ``.to()`` changes address / device."""
-    return tuple((id(t), t.data_ptr(), t._version, str(t.device)) for t in ts if t is not None)
+    return tuple((id(t), t.data_ptr(), t._version, t.device.index) for t in ts if t is not None)
 
 
 def _taps_major(conv: nn.Conv2d):

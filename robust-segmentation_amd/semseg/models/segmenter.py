@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .convnext_upernet import StochasticDepth, _up
+from .convnext_upernet import StochasticDepth, _fp32_bwd, _fp32_fwd, _up
 
 
 def _init(m):
@@ -36,7 +36,7 @@ class _AttentionHip(torch.autograd.Function):
     attention, deterministic backward); returns (B,T,H*64), the layout the output projection consumes."""
 
     @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    @_fp32_fwd
     def forward(ctx, qkv, scale):
         from .. import _native as N
         out, lse = N.attention_qkv(qkv, scale)
@@ -45,7 +45,7 @@ class _AttentionHip(torch.autograd.Function):
         return out
 
     @staticmethod
-    @torch.amp.custom_bwd(device_type="cuda")
+    @_fp32_bwd
     def backward(ctx, g):
         from .. import _native as N
         qkv, out, lse = ctx.saved_tensors

@@ -24,8 +24,10 @@ HW = H * W
 REPS = int(os.environ.get("SEA_PROFILE_REPS", "6"))
 
 
-def case(tag, kname, alg, moved):
-    print(f"CASE {tag} | {kname} | {alg} | {moved}", flush=True)
+def case(tag, kname, alg, moved, group=0, groups=1):
+    """kname: regular expression on the demangled kernel name; group/groups: the case's launches are the group-th of
+    `groups` equal runs of the matching launches in time order (cases that share one kernel instantiation)"""
+    print(f"CASE {tag} | {kname} | {alg} | {moved} | {group} | {groups}", flush=True)
 
 
 # ---- K2 ------------------------------------------------------------------------------------------------------------
@@ -46,14 +48,19 @@ for C in (21, 151):
                 for lg, y8, dl in sets:
                     N.loss_fwd_bwd(lg, y8, w, 1, 3, 1.0 / HW, grad, pred=pred, workspace=ws, dlogits=dl, defer=True)
             torch.cuda.synchronize()
-            kn = ("loss_nchw_split" if (grad and C == 151) else "loss_nchw_reg") if (grad or C <= 32) else "loss_nchw_fwd"
             dn = "float" if dtype == torch.float32 else "__hip_bfloat16"
-            case(f"K2 C={C} {str(dtype)[6:]} {'+grad' if grad else 'no-grad'} cold", f"{kn}<{dn}",
+            if grad and C == 151:
+                kn = f"loss_nchw_split<{dn}, 151,"
+            elif grad or C <= 32:
+                kn = f"loss_nchw_reg<{dn}, {C}, \\d+, {'true' if grad else 'false'},"
+            else:
+                kn = f"loss_nchw_fwd<{dn},"
+            case(f"K2 C={C} {str(dtype)[6:]} {'+grad' if grad else 'no-grad'} cold", kn,
                  B * HW * ((2 if grad else 1) * C * s + 16), B * HW * ((2 if grad else 1) * C * s + 2))
             del sets
 
 # ---- K2u (low-res logits: the working set is small by construction; the kernel is not HBM bound) ----------------------
-for C, hl, lab in ((21, 128, "x4"), (151, 128, "x4"), (151, 32, "x16")):
+for gi, (C, hl, lab) in enumerate(((21, 128, "x4"), (151, 128, "x4"), (151, 32, "x16"))):
     low = torch.randn(B, C, hl, hl, device="cuda") * 3
     y8 = torch.nn.functional.interpolate(low, size=(H, W), mode="bilinear").max(1)[1].to(torch.uint8)
     w = torch.rand(C, device="cuda")
@@ -63,7 +70,8 @@ for C, hl, lab in ((21, 128, "x4"), (151, 128, "x4"), (151, 32, "x16")):
         for r in range(REPS):
             N.loss_fwd_bwd_upsampled(low, y8, w, 1, 3, 1.0 / HW, grad, pred=pred, dlow=dlow if grad else None)
         torch.cuda.synchronize()
-    case(f"K2u C={C} {lab}", "loss_upsampled_kernel", B * HW * (2 * C * 4 + 16), B * (2 * C * hl * hl * 4 + 2 * HW))
+    case(f"K2u C={C} {lab} +grad", "loss_upsampled_kernel<true>", B * HW * (2 * C * 4 + 16), B * (2 * C * hl * hl * 4 + 2 * HW), gi, 3)
+    case(f"K2u C={C} {lab} no-grad", "loss_upsampled_kernel<false>", B * HW * (C * 4 + 16), B * (C * hl * hl * 4 + 2 * HW), gi, 3)
 
 # ---- K1 / K5 / K6 / K4 (25 MB tensors: ring of 16 sets = 2 GB) ----------------------------------------------------------------
 g = torch.Generator(device="cuda").manual_seed(1)
@@ -82,8 +90,8 @@ for r in range(2):
     for x, xa, xo, gr, out in ring:
         N.select_copy(fl, xa, gr, x, xo, out)
 torch.cuda.synchronize()
-case("K1 apgd_linf_step (4 in, 1 out) cold", "apgd_linf_step", 5 * n, 5 * n)
-case("K6 pgd_linf_step (3 in, 2 out) cold", "pgd_linf_step", 5 * n, 5 * n)
+case("K1 apgd_linf_step (4 in, 1 out) cold", "apgd_linf_step_v", 5 * n, 5 * n)
+case("K6 pgd_linf_step (3 in, 2 out) cold", "[^a]pgd_linf_step", 5 * n, 5 * n)
 case("K5 linf_project (2 in, 1 out) cold", "ew2_v4<1>", 3 * n, 3 * n)
 case("K4 select_copy (2 in, 3 out) cold", "select_copy_v", 5 * n, 5 * n)
 del ring

@@ -70,7 +70,7 @@ def run_case(C, dtype, grad, variants, rounds=9, hot=False):
     out = []
     for k, v in ts.items():
         ms = sorted(v)[len(v) // 2]
-        out.append(dict(kernel=f"K2 C={C} {str(dtype)[6:]} {'+grad' if grad else 'no-grad'} [{k}]", state="hot" if hot else "cold",
+        out.append(dict(kernel=f"K2 B={B} C={C} {str(dtype)[6:]} {'+grad' if grad else 'no-grad'} [{k}]", state="hot" if hot else "cold",
                         ms=ms, min_ms=min(v), algorithmic_MB=alg / 1e6, moved_MB=moved / 1e6,
                         frac_8TBps_algorithmic=alg / (ms * 1e-3) / 1e9 / PEAK, frac_8TBps_moved=moved / (ms * 1e-3) / 1e9 / PEAK))
         print(f"{out[-1]['kernel']:64s} {out[-1]['state']:4s} {ms * 1e3:8.1f} us  alg {out[-1]['frac_8TBps_algorithmic']:6.1%}"
@@ -84,7 +84,11 @@ def main():
     ap.add_argument("--dtypes", nargs="+", default=["float32", "bfloat16"])
     ap.add_argument("--json", default=None)
     ap.add_argument("--hot", action="store_true", help="also time the repeat-same-buffers state")
+    ap.add_argument("--batch", type=int, default=8, help="images per launch (BASELINE: 8)")
+    ap.add_argument("--defaults_only", action="store_true", help="only the shipped dispatch (no A/B variants)")
     args = ap.parse_args()
+    global B
+    B = args.batch
     N.lib()
     LEG = 0x1000
     res = []
@@ -123,13 +127,16 @@ def main():
             # no gradient: streaming variants vs the legacy register kernel
             v = {"default": 0, "stream CH4/5w": 0x100, "stream CH8/3w": 0x200, "stream CH6/4w": 0x300,
                  "stream CH2/8w": 0x400, "register kernel": LEG, "register kernel untuned": LEG | (15 << 4)}
+            if args.defaults_only:
+                v = {"default": 0}
             for hot in ([False, True] if args.hot else [False]):
                 res += run_case(C, dtype, False, v, hot=hot)
             # with gradient
-            if dtype == torch.float32:
             v = {"default": 0, "register kernel": LEG, "register kernel untuned": LEG | (15 << 4)}
             if C in (150, 151):
                 v.update({"split 5 waves": 0x100, "split 3 waves": 0x200, "split 4 waves": 0x300})
+            if args.defaults_only:
+                v = {"default": 0}
             for hot in ([False, True] if args.hot else [False]):
                 res += run_case(C, dtype, True, v, hot=hot)
     if args.json:

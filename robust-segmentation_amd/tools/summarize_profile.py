@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--fetch")
     ap.add_argument("--write")
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--title", default="B=8, C=21, 512x512, UperNet-ConvNeXt-T, fp32")
     ap.add_argument("--cases", help="stdout of tools/dev/profile_cases.py (CASE lines) to price --kernels / --fetch / --write rows")
     ap.add_argument("--sq", help="rocprofv3 --pmc SQ_* output directory (per-kernel medians are tabulated)")
     a = ap.parse_args()
@@ -70,11 +71,14 @@ def main():
     if a.bench:
         rows = list(csv.DictReader(open(one(a.bench, "*_kernel_trace.csv"))))
         rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-        k2 = [i for i, r in enumerate(rows) if any(t in r["Kernel_Name"] for t in ("loss_nchw_reg", "loss_nchw_split", "loss_nhwc", "loss_upsampled"))]
-        lo, hi = k2[a.warmup], k2[-1]      # k2[0] is step 0 of the attack, then `warmup` untimed steps
-        steps = len(k2) - 1 - a.warmup
-        win = rows[lo + 1: hi + 1]
-        t0, t1 = int(rows[lo]["End_Timestamp"]), int(rows[hi]["End_Timestamp"])
+        # one K1 launch per APGD step (none in step 0, none in the cold-launch ring bench.py runs after the timed
+        # region): the window runs from the first timed step's K1 to the last K4 copy of the last step
+        k1 = [i for i, r in enumerate(rows) if "apgd_linf_step" in r["Kernel_Name"]]
+        k4 = [i for i, r in enumerate(rows) if "select_copy" in r["Kernel_Name"]]
+        lo, hi = k1[a.warmup], max(i for i in k4)
+        steps = len(k1) - a.warmup
+        win = rows[lo: hi + 1]
+        t0, t1 = int(rows[lo]["Start_Timestamp"]), int(rows[hi]["End_Timestamp"])
         agg = collections.defaultdict(lambda: [0, 0])
         for r in win:
             agg[r["Kernel_Name"]][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
@@ -82,7 +86,7 @@ def main():
         tot = sum(v[0] for v in agg.values())
         with open(os.path.join(out_dir, f"{a.round}_bench_steady_state.md"), "w") as f:
             f.write(f"# bench.py steady state, rocprofv3 --kernel-trace ({a.round})\n\n")
-            f.write(f"Window: {steps} timed APGD steps (B=8, C=21, 512x512, UperNet-ConvNeXt-T, fp32).\n\n")
+            f.write(f"Window: {steps} timed APGD steps ({a.title}).\n\n")
             f.write(f"- wall per step: {(t1 - t0) / steps / 1e6:.3f} ms; kernel-busy per step: {tot / steps / 1e6:.3f} ms; "
                     f"launches per step: {sum(v[1] for v in agg.values()) / steps:.0f}\n\n")
             f.write("## attack-side HIP kernels (libsea_hip.so)\n\n| kernel | calls/step | avg us | ms/step | % of step |\n|---|---|---|---|---|\n")
@@ -163,23 +167,24 @@ def main():
             for line in open(a.cases):
                 if not line.startswith("CASE "):
                     continue
-                tag, kn, alg, moved = [t.strip() for t in line[5:].split("|")]
-                alg, moved = float(alg), float(moved)
-                durs = collections.defaultdict(list)
-                for r in trace:
-                    if kn in r["Kernel_Name"]:
-                        durs[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-                # the case's kernel: among the matching names, the one whose bytes/duration is plausible -> take all names, list each
-                for name, d in durs.items():
-                    if "cold" in tag and len(durs) > 1:
-                        # several instantiations share the substring (e.g. no-grad / grad): keep the one closest to 5 TB/s
-                        pass
-                    avg, mn = sum(d) / len(d) / 1e3, min(d) / 1e3
-                    pmc = ""
-                    if fe is not None and name in fe and name in wr:
-                        pmc = f"{(2 * med(fe[name]) + med(wr[name])) * 1024 / 1e6:.1f}"
-                    f.write(f"| {tag} | `{short(sea_key(name) or name, 70)}` | {len(d)} | {avg:.1f} | {mn:.1f} | {alg / 1e6:.1f} | {moved / 1e6:.1f} | "
-                            f"{pmc} | {alg / avg / 1e3 / 8000:.1%} | {moved / avg / 1e3 / 8000:.1%} |\n")
+                tag, kn, alg, moved, grp, ngrp = [t.strip() for t in line[5:].split("|")]
+                alg, moved, grp, ngrp = float(alg), float(moved), int(grp), int(ngrp)
+                pat = re.compile(kn)
+                hits = sorted((r for r in trace if pat.search(r["Kernel_Name"])), key=lambda r: int(r["Start_Timestamp"]))
+                if not hits:
+                    f.write(f"| {tag} | (no launch matched `{kn}`) | | | | | | | | |\n")
+                    continue
+                per = len(hits) // ngrp
+                hits = hits[grp * per: (grp + 1) * per]
+                name = hits[0]["Kernel_Name"]
+                d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in hits]
+                d = d[1:] if len(d) > 2 else d          # the first launch of a case pays the code-object load
+                avg, mn = sum(d) / len(d) / 1e3, min(d) / 1e3
+                pmc = ""
+                if fe is not None and ngrp == 1 and name in fe and name in wr:
+                    pmc = f"{(2 * med(fe[name]) + med(wr[name])) * 1024 / 1e6:.1f}"
+                f.write(f"| {tag} | `{short(sea_key(name) or name, 70)}` | {len(d)} | {avg:.1f} | {mn:.1f} | {alg / 1e6:.1f} | {moved / 1e6:.1f} | "
+                        f"{pmc} | {alg / avg / 1e3 / 8000:.1%} | {moved / avg / 1e3 / 8000:.1%} |\n")
 
     if a.sq:
         rows = collections.defaultdict(lambda: collections.defaultdict(list))

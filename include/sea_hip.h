@@ -292,6 +292,11 @@ int sea_nchw_to_nhwc(const float* in, const float* scale, float* out, int B, int
 int sea_nhwc_to_nchw(const float* in, const float* scale, const float* residual, float* out, int B, int C,
                      int64_t HW, void* stream);
 
+/* 2x2 patch gather / scatter for the trunk's 2x2 / stride-2 down-sampling convolutions (convnext_orig.py:118-124):
+ * pixels (B,H,W,C) channels_last <-> patch rows (B*H/2*W/2, 4*C) in (di, dj, c) order, so that the convolution is one GEMM
+ * (bitwise reproducible, unlike the MIOpen kernel it replaces).  inverse != 0: patches -> pixels (the backward). */
+int sea_patch2x2(const float* src, float* dst, int B, int H, int W, int C, int inverse, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * M7  fp32 multi-head attention on the matrix cores (v_mfma_f32_32x32x2_f32), flash formulation.
  *     replaces the explicit softmax(q k^T * scale) v of semseg/models/backbones/vit_encoder.py:106-127 (fp32 operands,

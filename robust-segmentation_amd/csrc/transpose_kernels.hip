@@ -94,3 +94,44 @@ extern "C" int sea_nhwc_to_nchw(const float* in, const float* scale, const float
                        (const float*)nullptr, out, (int)HW, C);
   SEA_RETURN_LAST();
 }
+
+// ---- 2x2 patch gather / scatter for the trunk's down-sampling convolutions (reference convnext_orig.py:118-124) ------------
+// (B,H,W,C) channels_last pixels <-> (B*H/2*W/2, 4*C) patch rows in (di, dj, c) order: the 2x2 / stride-2 convolution
+// is then ONE GEMM on the patch matrix.  Pure data movement, 16 bytes per lane, both sides contiguous C-vectors.
+namespace sea {
+template <bool INVERSE>
+__global__ __launch_bounds__(256) void patch2x2_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int H, int W,
+                                                       int C4, int64_t n4) {
+  const int Wh = W / 2, Hh = H / 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C4);
+    int64_t r = i / C4;
+    const int q = (int)(r & 3);
+    r >>= 2;
+    const int pj = (int)(r % Wh);
+    r /= Wh;
+    const int pi = (int)(r % Hh);
+    const int64_t b = r / Hh;
+    const int64_t pix = ((b * H + 2 * pi + (q >> 1)) * W + 2 * pj + (q & 1)) * C4 + c;
+    if (INVERSE)
+      dst[pix] = src[i];
+    else
+      dst[i] = src[pix];
+  }
+}
+}  // namespace sea
+
+// inverse == 0: pixels (B,H,W,C) -> patches (B*H/2*W/2, 4C); inverse != 0: patches -> pixels.  C % 4 == 0, H, W even.
+extern "C" int sea_patch2x2(const float* src, float* dst, int B, int H, int W, int C, int inverse, void* stream) {
+  SEA_CHECK_ARG(src && dst && B > 0 && H > 0 && W > 0 && C > 0 && (C % 4) == 0 && (H % 2) == 0 && (W % 2) == 0);
+  SEA_CHECK_ARG(((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0);
+  const int64_t n4 = (int64_t)B * H * W * (C / 4);
+  const int grid = sea::grid_for(n4, 256);
+  if (inverse)
+    hipLaunchKernelGGL((sea::patch2x2_kernel<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float4*)src,
+                       (float4*)dst, H, W, C / 4, n4);
+  else
+    hipLaunchKernelGGL((sea::patch2x2_kernel<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float4*)src,
+                       (float4*)dst, H, W, C / 4, n4);
+  SEA_RETURN_LAST();
+}

@@ -61,6 +61,7 @@ _SIGS = {
     "sea_gate_scale": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _vp]),
     "sea_upsample_bilinear_nhwc_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i64, _vp]),
     "sea_upsample_bilinear_nhwc_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i64, _vp]),
+    "sea_patch2x2": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sea_attention_fwd": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "sea_attention_bwd": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                _i64, _i64, _i64, _vp]),
@@ -111,7 +112,8 @@ def _dev(*ts):
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    # raw handle of the current stream of the current device (no Stream object: this runs ~600 times per attack step)
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -543,6 +545,26 @@ def nhwc_to_nchw(y, scale=None, residual=None):
     out = torch.empty(B, Cc, H, W, dtype=torch.float32, device=y.device)
     _check(lib().sea_nhwc_to_nchw(_p(_f32c(y)), _p(scale), _p(None if residual is None else _f32c(residual)), _p(out),
                                   B, Cc, H * W, _stream()), "sea_nhwc_to_nchw")
+    return out
+
+
+def patch2x2(x_nhwc):
+    """(B,H,W,C) contiguous fp32 -> (B*H/2*W/2, 4*C) rows of 2x2 patches in (di, dj, c) order"""
+    _dev(x_nhwc)
+    x_nhwc = _f32c(x_nhwc)
+    B, H, W, Cc = x_nhwc.shape
+    out = torch.empty(B * (H // 2) * (W // 2), 4 * Cc, dtype=torch.float32, device=x_nhwc.device)
+    _check(lib().sea_patch2x2(_p(x_nhwc), _p(out), B, H, W, Cc, 0, _stream()), "sea_patch2x2")
+    return out
+
+
+def unpatch2x2(rows, B, H, W):
+    """inverse of patch2x2: (B*H/2*W/2, 4*C) -> (B,H,W,C)"""
+    _dev(rows)
+    rows = _f32c(rows)
+    Cc = rows.shape[1] // 4
+    out = torch.empty(B, H, W, Cc, dtype=torch.float32, device=rows.device)
+    _check(lib().sea_patch2x2(_p(rows), _p(out), B, H, W, Cc, 1, _stream()), "sea_patch2x2")
     return out
 
 

@@ -337,7 +337,12 @@ class _PatchConv2x2(torch.autograd.Function):
         if cache.get("key") != key:
             cache.update(key=key, w=weight.detach().permute(0, 2, 3, 1).reshape(weight.shape[0], 4 * C).contiguous())
         wr = cache["w"]                                                        # (Cout, (di, dj, c))
-        patches = x.permute(0, 2, 3, 1).reshape(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, 4 * C)
+        from .. import _native as N
+        xn = x.permute(0, 2, 3, 1)
+        if xn.is_contiguous() and xn.dtype == torch.float32 and C % 4 == 0:
+            patches = N.patch2x2(xn)                                           # one 16-byte-per-lane gather pass
+        else:
+            patches = xn.reshape(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, 4 * C)
         y = torch.addmm(bias, patches, wr.t()) if bias is not None else patches @ wr.t()
         ctx.wr, ctx.shape = wr, (B, C, H, W)
         # under autocast the GEMM ran (and returned) bf16: the trunk's residual stream stays fp32
@@ -347,7 +352,12 @@ class _PatchConv2x2(torch.autograd.Function):
     def backward(ctx, gy):
         B, C, H, W = ctx.shape
         g = gy.permute(0, 2, 3, 1).reshape(-1, gy.shape[1])
-        gp = (g @ ctx.wr).float().view(B, H // 2, W // 2, 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, C)
+        rows = (g @ ctx.wr).float()
+        if C % 4 == 0 and rows.is_contiguous():
+            from .. import _native as N
+            gp = N.unpatch2x2(rows, B, H, W)
+        else:
+            gp = rows.view(B, H // 2, W // 2, 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, C)
         return gp.permute(0, 3, 1, 2), None, None, None
 
 
@@ -758,6 +768,29 @@ class PyramidPooling(nn.Module):
         return [_up(p, x.shape[2:]) for p in self.pooled(x)]
 
 
+class _ClassifierGemm(torch.autograd.Function):
+    """logits (B,cls,H,W) NCHW = W (cls,Cin) . y_b^T for a dense channels_last y (B,Cin,H,W), frozen weights.
+    The backward computes the input gradient directly in y's channels_last layout, g_b^T (P,cls) . W (cls,Cin):
+    letting autograd differentiate the transposed-view matmul instead costs a 268 MB transposing copy per step."""
+
+    @staticmethod
+    @_fp32_fwd
+    def forward(ctx, y, w2d, bias):
+        B, Cin, H, W = y.shape
+        out = torch.matmul(w2d, y.permute(0, 2, 3, 1).reshape(B, H * W, Cin).transpose(1, 2))
+        if bias is not None:
+            out += bias.view(1, -1, 1)
+        ctx.w2d, ctx.shape = w2d, (B, Cin, H, W)
+        return out.view(B, w2d.shape[0], H, W)
+
+    @staticmethod
+    @_fp32_bwd
+    def backward(ctx, g):
+        B, Cin, H, W = ctx.shape
+        gy = torch.matmul(g.reshape(B, g.shape[1], H * W).transpose(1, 2), ctx.w2d)      # (B, P, Cin) contiguous
+        return gy.view(B, H, W, Cin).permute(0, 3, 1, 2), None, None
+
+
 def _classify(conv: nn.Conv2d, y):
     """The head's final 1x1 convolution (uperforseg.py:262).  For frozen fp32 weights and a dense channels_last
     input it runs as one batched GEMM  W (cls, Cin) @ y_b^T (Cin, H*W)  whose output IS the NCHW logit tensor the
@@ -767,11 +800,7 @@ def _classify(conv: nn.Conv2d, y):
     if (y.is_cuda and y.dtype == torch.float32 and conv.kernel_size == (1, 1) and not torch.is_autocast_enabled()
             and not conv.weight.requires_grad and (conv.bias is None or not conv.bias.requires_grad)
             and N.cl_pixel_stride(y) == y.shape[1]):
-        B, Cin, H, W = y.shape
-        out = torch.matmul(conv.weight.view(conv.out_channels, Cin), y.permute(0, 2, 3, 1).reshape(B, H * W, Cin).transpose(1, 2))
-        if conv.bias is not None:
-            out = out + conv.bias.view(1, -1, 1)
-        return out.view(B, conv.out_channels, H, W)
+        return _ClassifierGemm.apply(y, conv.weight.view(conv.out_channels, y.shape[1]), conv.bias)
     return conv(y)
 
 

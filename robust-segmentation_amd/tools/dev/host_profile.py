@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Where does the HOST time of an attack step go?  cProfile over a few ApgdRun.step calls (enqueue only), plus the
+enqueue time per step next to the GPU time per step."""
+import cProfile
+import os
+import pstats
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "robust-segmentation_amd")]
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from semseg import attacker as A  # noqa: E402
+from semseg.utils.utils import ADE_WTS, VOC_WTS  # noqa: E402
+
+backbone, C = (sys.argv[1], int(sys.argv[2])) if len(sys.argv) > 2 else ("ConvNeXt-S_CVST", 151)
+dev = torch.device("cuda", 0)
+torch.backends.cudnn.benchmark = True
+model, x, y = bench.build_case(0, 8, C, backbone, dev)
+w = torch.tensor(VOC_WTS if C == 21 else ADE_WTS, device=dev)[:C]
+run = A.ApgdRun(model, x, y, 8 / 255, 40, "mask-ce-bal", "ce-avg", True, C, w, x.clone())
+run.start()
+for i in range(5):
+    run.step(i)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(5, 15):
+    run.step(i)
+t_enq = time.perf_counter() - t0
+torch.cuda.synchronize()
+t_all = time.perf_counter() - t0
+print(f"{backbone} C={C}: host enqueue {t_enq * 100:.2f} ms/step, wall {t_all * 100:.2f} ms/step")
+pr = cProfile.Profile()
+pr.enable()
+for i in range(15, 20):
+    run.step(i)
+pr.disable()
+torch.cuda.synchronize()
+st = pstats.Stats(pr)
+st.sort_stats("tottime").print_stats(28)

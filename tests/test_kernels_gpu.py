@@ -1005,3 +1005,27 @@ def test_segmenter_uses_hip_attention_and_matches_sdpa(N):
     S.USE_HIP_ATTENTION = True
     torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-4, atol=2e-5)
     torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-4, atol=2e-5)
+
+
+def test_patch_conv_2x2_matches_conv2d_and_is_deterministic(N):
+    """the trunk's 2x2 / stride-2 down-sampling convolutions as patch gather + GEMM (convnext_orig.py:118-124)"""
+    from semseg.models import convnext_upernet as M
+    torch.manual_seed(0)
+    for cin, cout, hw in ((96, 192, 32), (192, 384, 16), (8, 12, 6)):
+        conv = torch.nn.Conv2d(cin, cout, 2, stride=2).cuda()
+        for p in conv.parameters():
+            p.requires_grad_(False)
+        x = torch.randn(2, cin, hw, hw, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        g = torch.randn(2, cout, hw // 2, hw // 2, device="cuda")
+        y = M._PatchConv2x2.apply(x, conv.weight, conv.bias, {})
+        (gx,) = torch.autograd.grad(y, [x], grad_outputs=g)
+        y0 = conv(x)
+        (gx0,) = torch.autograd.grad(y0, [x], grad_outputs=g)
+        torch.testing.assert_close(y, y0, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(gx, gx0, rtol=1e-4, atol=1e-5)
+        y2 = M._PatchConv2x2.apply(x, conv.weight, conv.bias, {})
+        assert torch.equal(y, y2)
+        # the gather itself: exact
+        xn = x.detach().permute(0, 2, 3, 1).contiguous()
+        ref = xn.reshape(2, hw // 2, 2, hw // 2, 2, cin).permute(0, 1, 3, 2, 4, 5).reshape(-1, 4 * cin)
+        assert torch.equal(N.patch2x2(xn), ref) and torch.equal(N.unpatch2x2(ref.contiguous(), 2, hw, hw), xn)

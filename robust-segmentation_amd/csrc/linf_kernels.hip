@@ -28,26 +28,39 @@ __device__ __forceinline__ float apgd_elem(float x, float xa, float xo, float g,
   return box(t, x, eps);
 }
 
-// one image per blockIdx.y so the per-image step size is a scalar (SGPR) load
-__global__ __launch_bounds__(256) void apgd_linf_step_v4(const float4* __restrict__ x,
-                                                         const float4* __restrict__ xadv,
-                                                         const float4* __restrict__ xold,
-                                                         const float4* __restrict__ grad,
-                                                         const float* __restrict__ step_b, float eps,
-                                                         float a, float oma, float4* __restrict__ out,
-                                                         int64_t n4_per_img) {
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f4 apgd_elem4(f4 vx, f4 va, f4 vo, f4 vg, float st, float eps, float a, float oma) {
+  f4 r;
+  r.x = apgd_elem(vx.x, va.x, vo.x, vg.x, st, eps, a, oma);
+  r.y = apgd_elem(vx.y, va.y, vo.y, vg.y, st, eps, a, oma);
+  r.z = apgd_elem(vx.z, va.z, vo.z, vg.z, st, eps, a, oma);
+  r.w = apgd_elem(vx.w, va.w, vo.w, vg.w, st, eps, a, oma);
+  return r;
+}
+
+// one image per blockIdx.y so the per-image step size is a scalar (SGPR) load.  Two grid-stride positions per trip:
+// 8 independent 16-byte loads in flight per lane.  x_adv, x_old and grad are consumed exactly once per iteration
+// (non-temporal loads: they need not displace the clean image x, which every iteration re-reads, or the output,
+// which the model's first convolution reads next).
+__global__ __launch_bounds__(256) void apgd_linf_step_v4(const f4* __restrict__ x, const f4* __restrict__ xadv,
+                                                         const f4* __restrict__ xold, const f4* __restrict__ grad,
+                                                         const float* __restrict__ step_b, float eps, float a, float oma,
+                                                         f4* __restrict__ out, int64_t n4_per_img) {
   const int b = blockIdx.y;
   const float st = step_b[b];
   const int64_t base = (int64_t)b * n4_per_img;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4_per_img;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    float4 vx = x[base + i], va = xadv[base + i], vo = xold[base + i], vg = grad[base + i];
-    float4 r;
-    r.x = apgd_elem(vx.x, va.x, vo.x, vg.x, st, eps, a, oma);
-    r.y = apgd_elem(vx.y, va.y, vo.y, vg.y, st, eps, a, oma);
-    r.z = apgd_elem(vx.z, va.z, vo.z, vg.z, st, eps, a, oma);
-    r.w = apgd_elem(vx.w, va.w, vo.w, vg.w, st, eps, a, oma);
-    out[base + i] = r;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4_per_img; i += 2 * stride) {
+    const int64_t j = i + stride;
+    const bool hj = j < n4_per_img;
+    const int64_t jj = hj ? j : i;
+    const f4 vx0 = x[base + i], va0 = __builtin_nontemporal_load(xadv + base + i),
+             vo0 = __builtin_nontemporal_load(xold + base + i), vg0 = __builtin_nontemporal_load(grad + base + i);
+    const f4 vx1 = x[base + jj], va1 = __builtin_nontemporal_load(xadv + base + jj),
+             vo1 = __builtin_nontemporal_load(xold + base + jj), vg1 = __builtin_nontemporal_load(grad + base + jj);
+    out[base + i] = apgd_elem4(vx0, va0, vo0, vg0, st, eps, a, oma);
+    if (hj) out[base + j] = apgd_elem4(vx1, va1, vo1, vg1, st, eps, a, oma);
   }
 }
 
@@ -174,9 +187,8 @@ extern "C" int sea_apgd_linf_step(const float* x, const float* x_adv, const floa
     int cap = kMaxGridX / B;
     if (cap < 1) cap = 1;
     if (gx > cap) gx = cap;
-    hipLaunchKernelGGL(apgd_linf_step_v4, dim3(gx, B), dim3(256), 0, s, (const float4*)x,
-                       (const float4*)x_adv, (const float4*)x_old, (const float4*)grad, step_b, eps, a, oma,
-                       (float4*)out, n4);
+    hipLaunchKernelGGL(apgd_linf_step_v4, dim3(gx, B), dim3(256), 0, s, (const f4*)x, (const f4*)x_adv,
+                       (const f4*)x_old, (const f4*)grad, step_b, eps, a, oma, (f4*)out, n4);
   } else {
     int gx = grid_for(n_per_img, 256);
     int cap = kMaxGridX / B;

@@ -181,7 +181,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fuse-upsample", action="store_true",
                     help="force K2u (loss fused with the model's final bilinear upsample); default: the library's "
-                         "heuristic (fused for upsample factors >= 8, i.e. Segmenter; unfused for UperNet)")
+                         "heuristic (unfused unless the full-resolution logits + gradient exceed 24 GB)")
+    ap.add_argument("--no-fuse-upsample", action="store_true", help="force the model's own upsample + K2")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
@@ -216,9 +217,9 @@ def main():
     eps = args.eps / 255.0
 
     # default: the model's own upsample + the HBM-bound K2 (the kernel SURVEY 8d prices); --fuse-upsample
-    # switches to K2u, which is ~0.1 ms/step faster at C=21 and ~5 ms/step on Segmenter (x16, C=151)
+    # switches to K2u (no full-resolution logits in HBM; 0.8 ms/step slower on Segmenter x16, C=151)
     run = A.ApgdRun(model, x, y, eps, W + K + 1, args.loss, "ce-avg", True, C, weights, x.clone(),
-                    fuse_upsample=True if args.fuse_upsample else None)
+                    fuse_upsample=True if args.fuse_upsample else (False if args.no_fuse_upsample else None))
     run.start()
     for i in range(W):
         run.step(i)

@@ -47,6 +47,9 @@ extern "C" {
 /* library / build identification */
 int sea_abi_version(void);
 const char* sea_build_info(void);
+/* host only: the multiplier / shift the kernels use to divide a work index (< 2^31) by d without an integer division:
+ * n / d == (mulhi32(n, *m) + n) >> *s.  Exposed for the unit test of that arithmetic. */
+int sea_fastdiv_magic(uint32_t d, uint32_t* m, uint32_t* s);
 
 /* ------------------------------------------------------------------------------------------------
  * K1  APGD L-inf step with momentum.            replaces semseg/attacker.py:389-410, 456

@@ -83,14 +83,22 @@ __global__ __launch_bounds__(256) void dwconv7x7_kernel(const float* __restrict_
 // pointwise MLP consume the NHWC result as is.
 constexpr int DWN_STRIP = 8;
 
+//
+// Block order: a 1-D grid whose linear id is dealt round-robin to the 8 XCDs by the hardware.  Seven output rows read
+// the same input row, so neighbouring rows must meet in the SAME L2: block `id` works on unit (id % 8) * per_xcd + id / 8
+// of the (image, row, strip group) linearisation, i.e. every XCD sweeps its own contiguous band of rows (one image per
+// XCD at B = 8) and fetches it from the fabric once instead of all eight XCDs fetching everything.
 template <bool FLIP, bool BIAS>
 __global__ __launch_bounds__(256) void dwconv7x7_nhwc_kernel(const float4* __restrict__ x, const float4* __restrict__ wt,
                                                              const float4* __restrict__ bias, float4* __restrict__ y,
-                                                             int CG, int H, int W, int strips_per_block) {
+                                                             int CG, int H, int W, int strips_per_block, int gx, int units,
+                                                             int per_xcd) {
   const int cg = threadIdx.x % CG, ps = threadIdx.x / CG;
   if (ps >= strips_per_block) return;
-  const int b = blockIdx.z, oy = blockIdx.y;
-  const int ox0 = (blockIdx.x * strips_per_block + ps) * DWN_STRIP;
+  const int u = per_xcd ? (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  if (u >= units) return;
+  const int bx = u % gx, oy = (u / gx) % H, b = u / (gx * H);
+  const int ox0 = (bx * strips_per_block + ps) * DWN_STRIP;
   if (ox0 >= W) return;
   float4 acc[DWN_STRIP];
   const float4 b0 = BIAS ? bias[cg] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -139,17 +147,23 @@ extern "C" int sea_dwconv7x7_nhwc(const float* x, const float* wt, const float* 
   const int CG = C / 4;
   const int spb = 256 / CG;  // strips per block (>= 1 because CG <= 256)
   const int strips = (W + DWN_STRIP - 1) / DWN_STRIP;
-  dim3 grid((strips + spb - 1) / spb, H, B), block(256);
+  const int gx = (strips + spb - 1) / spb;
+  const int64_t units64 = (int64_t)gx * H * B;
+  SEA_CHECK_ARG(units64 < (1ll << 30));
+  const int units = (int)units64;
+  // flip bit 1 (value 2): plain linear block order (A/B switch for tools/dev/dwconv_bench.py)
+  const int per_xcd = (flip & 2) ? 0 : (units + 7) / 8;
+  dim3 grid(per_xcd ? per_xcd * 8 : units), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (flip)
+  if (flip & 1)
     hipLaunchKernelGGL((dwconv7x7_nhwc_kernel<true, false>), grid, block, 0, s, (const float4*)x, (const float4*)wt,
-                       (const float4*)nullptr, (float4*)y, CG, H, W, spb);
+                       (const float4*)nullptr, (float4*)y, CG, H, W, spb, gx, units, per_xcd);
   else if (bias)
     hipLaunchKernelGGL((dwconv7x7_nhwc_kernel<false, true>), grid, block, 0, s, (const float4*)x, (const float4*)wt,
-                       (const float4*)bias, (float4*)y, CG, H, W, spb);
+                       (const float4*)bias, (float4*)y, CG, H, W, spb, gx, units, per_xcd);
   else
     hipLaunchKernelGGL((dwconv7x7_nhwc_kernel<false, false>), grid, block, 0, s, (const float4*)x, (const float4*)wt,
-                       (const float4*)nullptr, (float4*)y, CG, H, W, spb);
+                       (const float4*)nullptr, (float4*)y, CG, H, W, spb, gx, units, per_xcd);
   SEA_RETURN_LAST();
 }
 

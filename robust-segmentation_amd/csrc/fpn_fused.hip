@@ -24,14 +24,14 @@ constexpr int kTB = 4;
 
 __global__ __launch_bounds__(256) void tap_gather_fwd_kernel(const float4* __restrict__ G, float4* __restrict__ extra,
                                                              int accumulate, int CG, int h, int w, int H, int W, float rh,
-                                                             float rw, int nBh, int nBw, int64_t total) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int cg = (int)(i % CG);
-    int64_t p = i / CG;
-    const int bx = (int)(p % nBw);
-    p /= nBw;
-    const int by = (int)(p % nBh);
-    const int b = (int)(p / nBh);
+                                                             float rw, int nBh, int nBw, int64_t total, int xcd,
+                                                             Divs3 dv) {
+  const IndexRange rg = xcd_range(total, xcd);
+  const bool fast = total < kFastIndexLimit;
+  for (int64_t i = rg.begin; i < rg.end; i += rg.stride) {
+    const Index4 ix = split_index(i, dv, fast);  // (cg, bx, by, b)
+    const int cg = ix.c0, bx = ix.c1, by = ix.c2;
+    const int b = (int)ix.c3;
     const int Y0 = by * kTB, X0 = bx * kTB;
     float4 acc[kTB][kTB];
     float4* eb = extra + (int64_t)b * H * W * CG + cg;
@@ -96,14 +96,13 @@ __global__ __launch_bounds__(256) void tap_gather_fwd_kernel(const float4* __res
 // one lane = (coarse pixel, 4 channels): a single pass over the (footprint + 1 ring) window of gz feeds all 9 taps
 __global__ __launch_bounds__(256) void tap_gather_bwd_kernel(const float4* __restrict__ gz, float4* __restrict__ dG, int CG,
                                                              int h, int w, int H, int W, float rh, float rw,
-                                                             int64_t total) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int cg = (int)(i % CG);
-    int64_t p = i / CG;
-    const int xq = (int)(p % w);
-    p /= w;
-    const int yq = (int)(p % h);
-    const int b = (int)(p / h);
+                                                             int64_t total, int xcd, Divs3 dv) {
+  const IndexRange rg = xcd_range(total, xcd);
+  const bool fast = total < kFastIndexLimit;
+  for (int64_t i = rg.begin; i < rg.end; i += rg.stride) {
+    const Index4 ix = split_index(i, dv, fast);  // (cg, xq, yq, b)
+    const int cg = ix.c0, xq = ix.c1, yq = ix.c2;
+    const int b = (int)ix.c3;
     const int Plo = first_dst_ge(yq - 1, rh, h, H), Phi = first_dst_ge(yq + 1, rh, h, H);
     const int Qlo = first_dst_ge(xq - 1, rw, w, W), Qhi = first_dst_ge(xq + 1, rw, w, W);
     const int R0 = max(Plo - 1, 0), R1 = min(Phi + 1, H), S0 = max(Qlo - 1, 0), S1 = min(Qhi + 1, W);
@@ -178,9 +177,9 @@ extern "C" int sea_tap_gather_fwd(const float* G, float* extra, int accumulate, 
   SEA_CHECK_ARG(((((uintptr_t)G) | ((uintptr_t)extra)) & 15) == 0);
   const int nBh = (H + kTB - 1) / kTB, nBw = (W + kTB - 1) / kTB;
   const int64_t total = (int64_t)B * nBh * nBw * (C / 4);
-  hipLaunchKernelGGL(tap_gather_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(tap_gather_fwd_kernel, dim3(grid_for_xcd(total, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const float4*)G, (float4*)extra, accumulate, C / 4, h, w, H, W, (float)h / (float)H,
-                     (float)w / (float)W, nBh, nBw, total);
+                     (float)w / (float)W, nBh, nBw, total, xcd_order_enabled(), divs3(C / 4, nBw, nBh));
   SEA_RETURN_LAST();
 }
 
@@ -189,8 +188,9 @@ extern "C" int sea_tap_gather_bwd(const float* gz, float* dG, int B, int C, int 
   SEA_CHECK_ARG(gz && dG && B > 0 && C > 0 && (C % 4) == 0 && h > 0 && w > 0 && H >= h && W >= w);
   SEA_CHECK_ARG(((((uintptr_t)gz) | ((uintptr_t)dG)) & 15) == 0);
   const int64_t total = (int64_t)B * h * w * (C / 4);
-  hipLaunchKernelGGL(tap_gather_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const float4*)gz, (float4*)dG, C / 4, h, w, H, W, (float)h / (float)H, (float)w / (float)W, total);
+  hipLaunchKernelGGL(tap_gather_bwd_kernel, dim3(grid_for_xcd(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)gz, (float4*)dG, C / 4, h, w, H, W, (float)h / (float)H, (float)w / (float)W, total,
+                     xcd_order_enabled(), divs3(C / 4, w, h));
   SEA_RETURN_LAST();
 }
 

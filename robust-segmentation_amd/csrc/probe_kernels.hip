@@ -75,3 +75,13 @@ extern "C" int sea_probe_stream_read(const void* src, float* sink, size_t bytes,
   hipLaunchKernelGGL((stream_read_kernel<8>), dim3(grid_for(n4, 256)), dim3(256), 0, (hipStream_t)stream, (const f4*)src, sink, n4);
   SEA_RETURN_LAST();
 }
+
+// The magic numbers the kernels divide work indices with (sea_common.h: FastDiv), for the host-side unit test:
+// for every n < 2^31:  n / d == (mulhi32(n, *m) + n) >> *s.
+extern "C" int sea_fastdiv_magic(uint32_t d, uint32_t* m, uint32_t* s) {
+  SEA_CHECK_ARG(d >= 1 && m && s);
+  const sea::FastDiv f = sea::fast_div(d);
+  *m = f.m;
+  *s = f.s;
+  return 0;
+}

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/sea_hip.h"
 
@@ -28,6 +29,106 @@ static inline int grid_for(int64_t work_items, int block) {
   if (g < 1) g = 1;
   if (g > kMaxGridX) g = kMaxGridX;
   return (int)g;
+}
+
+// ---- XCD-aware work order for grid-stride kernels with spatial reuse -------------------------------------------------
+// The dispatcher deals consecutive block ids round-robin to the 8 XCDs, each with a private 4 MB L2.  A kernel whose
+// neighbouring work items read overlapping input (stencils, bilinear footprints, Winograd tiles) therefore fetches every
+// shared pixel once per XCD from the fabric.  xcd_range() gives XCD k the k-th contiguous eighth of the linear index
+// space (one image at B = 8) and lets the blocks that landed on that XCD stride through it: overlapping reads meet in
+// one L2.  The launch must use grid_for_xcd() (a multiple of 8 blocks).  SEA_XCD_ORDER=0 restores the plain order.
+static inline int xcd_order_enabled() {
+  static const int on = [] {
+    const char* e = getenv("SEA_XCD_ORDER");
+    return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
+  }();
+  return on;
+}
+
+static inline int grid_for_xcd(int64_t work_items, int block) {
+  const int g = grid_for(work_items, block);
+  return (g + 7) / 8 * 8;
+}
+
+// ---- division by a launch-time constant: 3 instructions instead of the ~100 of a 64-bit (or ~25 of a 32-bit) integer
+// division.  Granlund-Montgomery round-up method with the 33-bit magic 2^32 + m, s = ceil(log2 d); exact for every
+// dividend below 2^31 (the sum below cannot wrap).  Kernels that decompose a linear work index use it whenever the
+// index space is smaller than 2^31 (kFastIndexLimit) and fall back to 64-bit arithmetic otherwise.
+struct FastDiv {
+  uint32_t d, m, s;
+};
+
+static inline FastDiv fast_div(uint32_t d) {  // d >= 1
+  FastDiv f;
+  f.d = d;
+  uint32_t s = 0;
+  while ((1ull << s) < d) ++s;
+  f.s = s;
+  f.m = (uint32_t)(((1ull << 32) * ((1ull << s) - d)) / d + 1);
+  return f;
+}
+
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv f) { return (__umulhi(n, f.m) + n) >> f.s; }
+
+// linear index -> (c0, c1, c2, c3) with i = ((c3 * n2 + c2) * n1 + c1) * n0 + c0
+struct Divs3 {
+  FastDiv f0, f1, f2;
+};
+
+static inline Divs3 divs3(int64_t n0, int64_t n1, int64_t n2) {
+  Divs3 d;
+  d.f0 = fast_div((uint32_t)n0);
+  d.f1 = fast_div((uint32_t)n1);
+  d.f2 = fast_div((uint32_t)n2);
+  return d;
+}
+
+struct Index4 {
+  int c0, c1, c2;
+  int64_t c3;
+};
+
+__device__ __forceinline__ Index4 split_index(int64_t i, const Divs3 d, bool fast) {
+  Index4 r;
+  if (fast) {  // wave-uniform: the whole index space is below 2^31
+    const uint32_t n = (uint32_t)i, q0 = fdiv(n, d.f0), q1 = fdiv(q0, d.f1), q2 = fdiv(q1, d.f2);
+    r.c0 = (int)(n - q0 * d.f0.d);
+    r.c1 = (int)(q0 - q1 * d.f1.d);
+    r.c2 = (int)(q1 - q2 * d.f2.d);
+    r.c3 = q2;
+  } else {
+    int64_t p = i;
+    r.c0 = (int)(p % d.f0.d);
+    p /= d.f0.d;
+    r.c1 = (int)(p % d.f1.d);
+    p /= d.f1.d;
+    r.c2 = (int)(p % d.f2.d);
+    r.c3 = p / d.f2.d;
+  }
+  return r;
+}
+
+constexpr int64_t kFastIndexLimit = (1ll << 31) - (1ll << 24);  // room for the rounding of xcd_range chunks
+
+struct IndexRange {
+  int64_t begin, end, stride;
+};
+
+__device__ __forceinline__ IndexRange xcd_range(int64_t total, int on) {
+  IndexRange r;
+  if (!on) {
+    r.begin = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    r.end = total;
+    r.stride = (int64_t)gridDim.x * blockDim.x;
+    return r;
+  }
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, per = gridDim.x >> 3;
+  const int64_t chunk = (((total + 7) >> 3) + blockDim.x - 1) / blockDim.x * blockDim.x;
+  const int64_t b0 = xcd * chunk;
+  r.begin = b0 + (int64_t)local * blockDim.x + threadIdx.x;
+  r.end = b0 + chunk < total ? b0 + chunk : total;
+  r.stride = (int64_t)per * blockDim.x;
+  return r;
 }
 
 // label loads: any integer width; ignore label = -1 (255 for uint8); returns -1 for ignored

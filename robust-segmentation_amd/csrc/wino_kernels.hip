@@ -88,16 +88,17 @@ template <int M, int VEC>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, const float* __restrict__ gate,
                                                          const float* __restrict__ scale, float* __restrict__ V, int C,
                                                          int H, int W, int nTh, int nTw, int64_t T, int64_t total,
-                                                         int64_t xps, int64_t vts) {
+                                                         int64_t xps, int64_t vts, int xcd, Divs3 dv) {
   constexpr int A = M + 2;
-  const int CG = C / VEC;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int cg = (int)(idx % CG);
-    const int64_t t = idx / CG;
-    const int tx = (int)(t % nTw);
-    const int ty = (int)((t / nTw) % nTh);
-    const int b = (int)(t / ((int64_t)nTw * nTh));
+  const bool fast = total < kFastIndexLimit;
+  // plain order by default: the transform writes 2.25x what it reads, and the XCD-contiguous order measured 4-9 %
+  // slower (profiles/r2_xcd_order_ab.log); SEA_XCD_ORDER=2 turns it on for this kernel
+  const IndexRange rg = xcd_range(total, xcd);
+  for (int64_t idx = rg.begin; idx < rg.end; idx += rg.stride) {
+    const Index4 ix = split_index(idx, dv, fast);  // (cg, tx, ty, b)
+    const int cg = ix.c0, tx = ix.c1, ty = ix.c2;
+    const int b = (int)ix.c3;
+    const int64_t t = ((int64_t)b * nTh + ty) * nTw + tx;
     const int y0 = ty * M - 1, x0 = tx * M - 1;
     const int64_t base = (int64_t)b * H * W * C + (int64_t)cg * VEC;
     const float* xb = x + (int64_t)b * H * W * xps + (int64_t)cg * VEC;  // x may be a channel slice: pixel stride xps
@@ -156,16 +157,15 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ bias, int relu,
                                                           float* __restrict__ y, int C, int H, int W, int nTh, int nTw,
-                                                          int64_t T, int64_t total) {
+                                                          int64_t T, int64_t total, Divs3 dv) {
   constexpr int A = M + 2;
-  const int CG = C / VEC;
+  const bool fast = total < kFastIndexLimit;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
-    const int cg = (int)(idx % CG);
-    const int64_t t = idx / CG;
-    const int tx = (int)(t % nTw);
-    const int ty = (int)((t / nTw) % nTh);
-    const int b = (int)(t / ((int64_t)nTw * nTh));
+    const Index4 ix = split_index(idx, dv, fast);  // (cg, tx, ty, b)
+    const int cg = ix.c0, tx = ix.c1, ty = ix.c2;
+    const int b = (int)ix.c3;
+    const int64_t t = ((int64_t)b * nTh + ty) * nTw + tx;
     const float* mb = Mx + t * C + (int64_t)cg * VEC;
     // rows first, one Winograd-domain row at a time: tmp[p][j] = sum_i At[p][i] m[i][j]
     float tmp[M][A][VEC];
@@ -284,12 +284,12 @@ extern "C" int sea_wino_input_transform(const float* x, int64_t x_pixel_stride, 
   SEA_CHECK_ARG(((((uintptr_t)x) | ((uintptr_t)V) | ((uintptr_t)gate)) & 15) == 0);
   if (m == 2) {
     const int64_t total = T * (C / 4);
-    hipLaunchKernelGGL((wino_input_kernel<2, 4>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, gate,
-                       scale, V, C, H, W, nTh, nTw, T, total, x_pixel_stride, v_tile_stride);
+    hipLaunchKernelGGL((wino_input_kernel<2, 4>), dim3(grid_for_xcd(total, 256)), dim3(256), 0, (hipStream_t)stream, x, gate,
+                       scale, V, C, H, W, nTh, nTw, T, total, x_pixel_stride, v_tile_stride, xcd_order_enabled() == 2, divs3(C / 4, nTw, nTh));
   } else {
     const int64_t total = T * (C / 2);
-    hipLaunchKernelGGL((wino_input_kernel<4, 2>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, gate,
-                       scale, V, C, H, W, nTh, nTw, T, total, x_pixel_stride, v_tile_stride);
+    hipLaunchKernelGGL((wino_input_kernel<4, 2>), dim3(grid_for_xcd(total, 256)), dim3(256), 0, (hipStream_t)stream, x, gate,
+                       scale, V, C, H, W, nTh, nTw, T, total, x_pixel_stride, v_tile_stride, xcd_order_enabled() == 2, divs3(C / 2, nTw, nTh));
   }
   SEA_RETURN_LAST();
 }
@@ -303,11 +303,11 @@ extern "C" int sea_wino_output_transform(const float* Mx, const float* addend, c
   if (m == 2) {
     const int64_t total = T * (C / 4);
     hipLaunchKernelGGL((wino_output_kernel<2, 4>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, Mx,
-                       addend, scale, bias, relu, y, C, H, W, nTh, nTw, T, total);
+                       addend, scale, bias, relu, y, C, H, W, nTh, nTw, T, total, divs3(C / 4, nTw, nTh));
   } else {
     const int64_t total = T * (C / 2);
     hipLaunchKernelGGL((wino_output_kernel<4, 2>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, Mx,
-                       addend, scale, bias, relu, y, C, H, W, nTh, nTw, T, total);
+                       addend, scale, bias, relu, y, C, H, W, nTh, nTw, T, total, divs3(C / 2, nTw, nTh));
   }
   SEA_RETURN_LAST();
 }

@@ -25,6 +25,7 @@ _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 _SIGS = {
     "sea_abi_version": (C.c_int, []),
     "sea_build_info": (C.c_char_p, []),
+    "sea_fastdiv_magic": (_i, [C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "sea_apgd_linf_step": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _i, _i64, _vp]),
     "sea_linf_random_start": (_i, [_vp, _vp, _f, _vp, _i64, _vp]),
     "sea_linf_project": (_i, [_vp, _vp, _f, _vp, _i64, _vp]),

@@ -272,12 +272,15 @@ def _input_grad(logits, x_in, dlogits):
 
 
 # K2u (loss fused with the model's final bilinear upsample; needs `model.forward_lowres`).
-#   "auto": fuse when the upsample factor is >= 8.  Measured on MI355X (B=8, 512x512): Segmenter ViT-S/16, C=151
-#           26.1 ms/step fused vs 32.6 ms unfused (the x16 upsample of a 1.27 GB logit tensor and its backward
-#           dominate); UperNet x4: the streaming upsample kernels M2 + K2 are as fast (C=21) or faster (C=151).
-#   True / False force it.  K2u also never materialises the (B,C,H,W) logits and their gradient
-#   (2.5 GB at B=8, C=151).
+#   "auto": fuse only when the materialised full-resolution logits and their gradient would not fit comfortably
+#           (more than FUSE_UPSAMPLE_AUTO_BYTES together): K2u never materialises them (2.5 GB at B=8, C=151, 512^2).
+#           Measured on MI355X (B=8, 512x512, fp32, profiles/r2_final_bench.log ff.): since the power-of-two
+#           up-sampling kernels (M2) and the class-split K2 of round 2 the unfused path is the faster one everywhere:
+#           Segmenter ViT-S/16 x16, C=151: 22.4 ms/step unfused vs 23.2 ms fused (round 1: 32.6 vs 26.1);
+#           UperNet x4: C=21 equal, C=151 unfused faster.
+#   True / False force it.
 FUSE_UPSAMPLE = "auto"
+FUSE_UPSAMPLE_AUTO_BYTES = 24 * 2 ** 30
 
 
 class ApgdRun:
@@ -297,7 +300,8 @@ class ApgdRun:
             if probe is None:
                 fuse_upsample = False
             elif fuse_upsample == "auto":
-                fuse_upsample = x.shape[-1] / probe[0].shape[-1] >= 8
+                full = 2 * 4 * x.shape[0] * probe[0].shape[1] * x.shape[-2] * x.shape[-1]  # logits + gradient, fp32
+                fuse_upsample = full > FUSE_UPSAMPLE_AUTO_BYTES
         else:
             fuse_upsample = False
         self.fused = bool(fuse_upsample)

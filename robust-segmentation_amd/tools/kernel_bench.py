@@ -167,7 +167,7 @@ def main():
 
     # ---------------- M2 / M1 (model side) ---------------------------------------------------------------
     import torch.nn.functional as F
-    for Cc, hl, Hh in ((512, 64, 128), (512, 32, 128), (512, 16, 128), (512, 32, 64), (512, 16, 32), (21, 128, 512)):
+    for Cc, hl, Hh in ((512, 64, 128), (512, 32, 128), (512, 16, 128), (512, 32, 64), (512, 16, 32), (21, 128, 512), (151, 128, 512), (151, 32, 512)):
         xin = torch.randn(B, Cc, hl, hl, device="cuda")
         gy = torch.randn(B, Cc, Hh, Hh, device="cuda")
         t = timeit({

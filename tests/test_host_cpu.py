@@ -6,6 +6,7 @@ import random
 import re
 import subprocess
 
+import numpy as np
 import pytest
 import torch
 
@@ -36,6 +37,26 @@ def test_library_exports_every_declared_symbol(native):
     assert lib.sea_abi_version() == 1
     assert b"gfx950" in lib.sea_build_info()
     assert lib.sea_loss_workspace_bytes(8, 512 * 512) == (8 * 2048 + 1) * 16  # header + one record per 128-pixel tile (the smallest tile any K2 variant uses)
+
+
+def test_fastdiv_magic_divides_exactly(native):
+    """the multiplier / shift pairs the kernels use instead of integer division (csrc/sea_common.h: FastDiv)"""
+    import ctypes as C
+    lib = native.lib()
+    rng = np.random.default_rng(0)
+    ds = np.unique(np.concatenate([np.arange(1, 300), 2 ** np.arange(0, 31), 2 ** np.arange(1, 31) - 1,
+                                   2 ** np.arange(1, 30) + 1, rng.integers(1, 2 ** 31 - 1, 300),
+                                   [24, 96, 151, 171, 1025, 262144, 2 ** 31 - 1]]))
+    for d in ds:
+        m, s = C.c_uint32(), C.c_uint32()
+        assert lib.sea_fastdiv_magic(int(d), C.byref(m), C.byref(s)) == 0
+        n = np.unique(np.concatenate([rng.integers(0, 2 ** 31, 2000), np.arange(0, 64), [2 ** 31 - 1, 2 ** 31 - 2],
+                                      np.arange(1, 40) * d - 1, np.arange(1, 40) * d])).astype(np.uint64)
+        n = n[n < 2 ** 31]
+        q = (((n * np.uint64(m.value)) >> np.uint64(32)) + n) >> np.uint64(s.value)
+        assert np.all(q < 2 ** 32)  # the 32-bit sum in the kernel cannot wrap
+        np.testing.assert_array_equal(q, n // np.uint64(d))
+    assert lib.sea_fastdiv_magic(0, C.byref(m), C.byref(s)) == 1
 
 
 def test_header_is_plain_c():

@@ -395,7 +395,13 @@ def test_fused_and_unfused_attack_agree(N):
 # ------------------------------------------------------------------------------------------------ M2
 @pytest.mark.parametrize("case", [(2, 8, 16, 16, 32, 32), (1, 4, 32, 32, 128, 128), (2, 3, 16, 16, 128, 128),
                                   (1, 5, 1, 1, 16, 16), (1, 5, 3, 3, 16, 16), (2, 2, 6, 6, 16, 16),
-                                  (1, 7, 30, 30, 119, 119), (1, 2, 13, 11, 50, 45), (1, 1, 9, 7, 9, 7)])
+                                  (1, 7, 30, 30, 119, 119), (1, 2, 13, 11, 50, 45), (1, 1, 9, 7, 9, 7),
+                                  # power-of-two factors take the specialised kernels: edges, 1-wide maps, x16
+                                  (2, 3, 8, 8, 128, 128), (1, 2, 2, 3, 8, 12), (1, 3, 5, 1, 20, 4), (1, 2, 1, 6, 2, 12),
+                                  (1, 2, 3, 2, 48, 32), (1, 3, 7, 5, 56, 40), (1, 2, 4, 8, 8, 32), (1, 2, 5, 3, 10, 6),
+                                  # row-streaming backward (output width 128 ... 1024), ragged bands
+                                  (1, 2, 5, 64, 20, 256), (1, 1, 3, 32, 48, 512), (1, 1, 7, 512, 14, 1024),
+                                  (1, 2, 9, 16, 72, 128), (2, 2, 33, 128, 132, 512), (1, 1, 1, 32, 16, 512)])
 def test_upsample_bilinear_forward_backward(N, case):
     import torch.nn.functional as F
     B, C, h, w, H, W = case
@@ -412,8 +418,14 @@ def test_upsample_bilinear_forward_backward(N, case):
     torch.testing.assert_close(y.cpu(), ref32, rtol=1e-5, atol=2e-5)
     torch.testing.assert_close(y.cpu().double(), ref.detach(), rtol=1e-5, atol=2e-4)
     gx = N.upsample_bilinear_backward(dev(gy), (h, w))
-    torch.testing.assert_close(gx.cpu().double(), gx_ref, rtol=1e-5, atol=1e-3)
+    pow2 = H == W * h // w and H // h in (2, 4, 8, 16) and H % h == 0 and W % w == 0 and W // w == H // h
+    torch.testing.assert_close(gx.cpu().double(), gx_ref, rtol=1e-5, atol=5e-5 if pow2 else 1e-3)
     assert torch.equal(gx, N.upsample_bilinear_backward(dev(gy), (h, w)))  # deterministic gather
+    if pow2:  # exact dyadic weights: inf stays inf (no 0 * inf from masked window parts)
+        gy2 = gy.clone()
+        gy2[0, 0, 0, 0] = float("inf")
+        gx2 = N.upsample_bilinear_backward(dev(gy2), (h, w)).cpu()
+        assert torch.isinf(gx2[0, 0, 0, 0]) and not torch.isnan(gx2).any()
 
 
 @pytest.mark.parametrize("case", [(2, 8, 16, 16, 32, 32), (1, 4, 32, 32, 128, 128), (2, 12, 16, 16, 128, 128),

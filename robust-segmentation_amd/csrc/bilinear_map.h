@@ -31,6 +31,30 @@ __device__ __forceinline__ int first_dst_ge(int t, float r, int n_in, int n_out)
   return d;
 }
 
+// Power-of-two factor S in this axis (n_out = S * n_in): with t = dst + S/2 the source pair is i0 = (t >> log2 S) - 1
+// (negative: clamped to 0 with lambda = 0, exactly what the clamp of src does) and lambda = ((t & (S-1)) + 0.5) / S.
+// r = 1/S and every intermediate of axis_map_u are exact in float for such factors: identical results, integer ops only.
+// S = 0 selects the general float rule.
+template <int S>
+__device__ __forceinline__ AxisMapU axis_map_p2(int dst, float r, int n_in) {
+  if constexpr (S == 0) {
+    return axis_map_u(dst, r, n_in);
+  } else {
+    static_assert(S == 2 || S == 4 || S == 8 || S == 16, "supported factors");
+    constexpr int LOG = S == 2 ? 1 : S == 4 ? 2 : S == 8 ? 3 : 4;
+    const int t = dst + S / 2;
+    AxisMapU m;
+    m.i0 = (t >> LOG) - 1;
+    m.lam = ((float)(t & (S - 1)) + 0.5f) * (1.f / (float)S);
+    if (m.i0 < 0) {
+      m.i0 = 0;
+      m.lam = 0.f;
+    }
+    m.i1 = min(m.i0 + 1, n_in - 1);
+    return m;
+  }
+}
+
 // weight of source index `src` in the interpolation of destination index `dst`
 __device__ __forceinline__ float axis_coef(int dst, int src, float r, int n_in) {
   const AxisMapU m = axis_map_u(dst, r, n_in);

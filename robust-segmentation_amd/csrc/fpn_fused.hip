@@ -22,6 +22,7 @@ namespace sea {
 // bound by L2 bandwidth at 16 TB/s of corner re-reads).
 constexpr int kTB = 4;
 
+template <int S>  // S = 4 / 8: that power-of-two factor in both axes (integer source map), 0: any factor >= 3
 __global__ __launch_bounds__(256) void tap_gather_fwd_kernel(const float4* __restrict__ G, float4* __restrict__ extra,
                                                              int accumulate, int CG, int h, int w, int H, int W, float rh,
                                                              float rw, int nBh, int nBw, int64_t total, int xcd,
@@ -39,24 +40,27 @@ __global__ __launch_bounds__(256) void tap_gather_fwd_kernel(const float4* __res
     for (int py = 0; py < kTB; ++py)
 #pragma unroll
       for (int px = 0; px < kTB; ++px)
-        acc[py][px] = (accumulate && Y0 + py < H && X0 + px < W) ? eb[((int64_t)(Y0 + py) * W + X0 + px) * CG]
+        acc[py][px] = (accumulate && Y0 + py < H && X0 + px < W) ? eb[(uint32_t)(((Y0 + py) * W + X0 + px) * CG)]
                                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4* Gb = G + (int64_t)b * h * w * 9 * CG + cg;
 #pragma unroll 1  // one tap at a time: 9 loads in flight, ~150 VGPRs (fully unrolled the 81 loads spill)
     for (int tap = 0; tap < 9; ++tap) {
       const int a = tap / 3, bq = tap - a * 3;
       // wy[py][k] = weight of coarse row ib + k for the sample row P = Y0+py+a-1 (0 outside the image); same for columns
-      const int ib = axis_map_u(min(max(Y0 + a - 1, 0), H - 1), rh, h).i0;
-      const int jb = axis_map_u(min(max(X0 + bq - 1, 0), W - 1), rw, w).i0;
+      const int ib = axis_map_p2<S>(min(max(Y0 + a - 1, 0), H - 1), rh, h).i0;
+      const int jb = axis_map_p2<S>(min(max(X0 + bq - 1, 0), W - 1), rw, w).i0;
       float wy[kTB][3], wx[kTB][3];
 #pragma unroll
       for (int q = 0; q < kTB; ++q) {
         const int P = Y0 + q + a - 1, Q = X0 + q + bq - 1;
         const bool oky = P >= 0 && P < H, okx = Q >= 0 && Q < W;
+        const AxisMapU mp = axis_map_p2<S>(P, rh, h), mq = axis_map_p2<S>(Q, rw, w);  // one map per sample row / column
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-          wy[q][k] = oky ? axis_coef(P, ib + k, rh, h) : 0.f;
-          wx[q][k] = okx ? axis_coef(Q, jb + k, rw, w) : 0.f;
+          const float cy = ((mp.i0 == ib + k) ? (1.f - mp.lam) : 0.f) + ((mp.i1 == ib + k) ? mp.lam : 0.f);
+          const float cx = ((mq.i0 == jb + k) ? (1.f - mq.lam) : 0.f) + ((mq.i1 == jb + k) ? mq.lam : 0.f);
+          wy[q][k] = oky ? cy : 0.f;
+          wx[q][k] = okx ? cx : 0.f;
         }
       }
       float4 g[3][3];
@@ -64,7 +68,7 @@ __global__ __launch_bounds__(256) void tap_gather_fwd_kernel(const float4* __res
       for (int k = 0; k < 3; ++k)
 #pragma unroll
         for (int l = 0; l < 3; ++l)
-          g[k][l] = Gb[(((int64_t)min(ib + k, h - 1) * w + min(jb + l, w - 1)) * 9 + tap) * CG];
+          g[k][l] = Gb[(uint32_t)(((min(ib + k, h - 1) * w + min(jb + l, w - 1)) * 9 + tap) * CG)];
 #pragma unroll
       for (int py = 0; py < kTB; ++py) {
         float4 t[3];
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(256) void tap_gather_fwd_kernel(const float4* __res
     for (int py = 0; py < kTB; ++py)
 #pragma unroll
       for (int px = 0; px < kTB; ++px)
-        if (Y0 + py < H && X0 + px < W) eb[((int64_t)(Y0 + py) * W + X0 + px) * CG] = acc[py][px];
+        if (Y0 + py < H && X0 + px < W) eb[(uint32_t)(((Y0 + py) * W + X0 + px) * CG)] = acc[py][px];
   }
 }
 
@@ -153,6 +157,97 @@ __global__ __launch_bounds__(256) void tap_gather_bwd_kernel(const float4* __res
   }
 }
 
+// Power-of-two factor S (x4 and x8 in UperNet): the footprint of coarse pixel (yq, xq) is the 2S x 2S window at
+// (S*yq - S/2, S*xq - S/2) with constant separable weights (upsample_kernels.hip: upsample_bwd_pow2_kernel), so the
+// window + ring of gz is (2S+2)^2: a row is 2S+2 independent 16-byte loads and 3 x 2S fused multiply-adds per channel
+// with compile-time weights, instead of one dependent load and three float source-index evaluations per element.
+template <int S>
+__device__ __forceinline__ float pow2_tap_weight(int t, bool e_lo, bool e_hi) {
+  // weight of window position t in [0, 2S) (0 outside); e_lo / e_hi: the coarse pixel is the first / last of its axis
+  if (t < 0 || t >= 2 * S) return 0.f;
+  constexpr float inv = 1.f / (float)S;
+  const float c = (t < S) ? ((float)t + 0.5f) * inv : ((float)(2 * S - t) - 0.5f) * inv;
+  if (t < S / 2) return e_lo ? 0.f : c;
+  if (t < S) return e_lo ? 1.f : c;
+  if (t < 3 * S / 2) return e_hi ? 1.f : c;
+  return e_hi ? 0.f : c;
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void tap_gather_bwd_pow2_kernel(const float4* __restrict__ gz, float4* __restrict__ dG,
+                                                                  int CG, int h, int w, int64_t total, int xcd,
+                                                                  Divs3 dv) {
+  constexpr int T = 2 * S, TW = T + 2;
+  const int H = h * S, W = w * S;
+  const IndexRange rg = xcd_range(total, xcd);
+  const bool fast = total < kFastIndexLimit;
+  for (int64_t i = rg.begin; i < rg.end; i += rg.stride) {
+    const Index4 ix = split_index(i, dv, fast);  // (cg, xq, yq, b)
+    const int cg = ix.c0, xq = ix.c1, yq = ix.c2;
+    const int b = (int)ix.c3;
+    const bool eL = xq == 0, eR = xq == w - 1, eT = yq == 0, eB = yq == h - 1;
+    const int Q0 = S * xq - S / 2 - 1, R0 = S * yq - S / 2 - 1;  // window + ring origin
+    float wxe[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) wxe[t] = pow2_tap_weight<S>(t, eL, eR);
+    const float4* gb = gz + ((int64_t)b * H * W + Q0) * CG + cg;
+    float4 acc[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int bq = 0; bq < 3; ++bq) acc[a][bq] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+    for (int u = 0; u < TW; ++u) {
+      const int R = R0 + u;
+      if (R < 0 || R >= H) continue;
+      // tap a reads gz row R as sample row P = R + a - 1, window position t = u + a - 2
+      const float wy0 = pow2_tap_weight<S>(u - 2, eT, eB), wy1 = pow2_tap_weight<S>(u - 1, eT, eB),
+                  wy2 = pow2_tap_weight<S>(u, eT, eB);
+      const float4* row = gb + (int64_t)R * W * CG;
+      float4 g[TW];
+#pragma unroll
+      for (int v = 0; v < TW; ++v) {
+        const int Q = Q0 + v;
+        g[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (Q >= 0 && Q < W) g[v] = row[(int64_t)v * CG];
+      }
+      float4 rb[3];
+#pragma unroll
+      for (int bq = 0; bq < 3; ++bq) {
+        rb[bq] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {  // sample column Q' = window position t reads gz column v = t + 2 - bq
+          const int v = t + 2 - bq;
+          rb[bq].x = fmaf(wxe[t], g[v].x, rb[bq].x);
+          rb[bq].y = fmaf(wxe[t], g[v].y, rb[bq].y);
+          rb[bq].z = fmaf(wxe[t], g[v].z, rb[bq].z);
+          rb[bq].w = fmaf(wxe[t], g[v].w, rb[bq].w);
+        }
+      }
+#pragma unroll
+      for (int bq = 0; bq < 3; ++bq) {
+        acc[0][bq].x = fmaf(wy0, rb[bq].x, acc[0][bq].x);
+        acc[0][bq].y = fmaf(wy0, rb[bq].y, acc[0][bq].y);
+        acc[0][bq].z = fmaf(wy0, rb[bq].z, acc[0][bq].z);
+        acc[0][bq].w = fmaf(wy0, rb[bq].w, acc[0][bq].w);
+        acc[1][bq].x = fmaf(wy1, rb[bq].x, acc[1][bq].x);
+        acc[1][bq].y = fmaf(wy1, rb[bq].y, acc[1][bq].y);
+        acc[1][bq].z = fmaf(wy1, rb[bq].z, acc[1][bq].z);
+        acc[1][bq].w = fmaf(wy1, rb[bq].w, acc[1][bq].w);
+        acc[2][bq].x = fmaf(wy2, rb[bq].x, acc[2][bq].x);
+        acc[2][bq].y = fmaf(wy2, rb[bq].y, acc[2][bq].y);
+        acc[2][bq].z = fmaf(wy2, rb[bq].z, acc[2][bq].z);
+        acc[2][bq].w = fmaf(wy2, rb[bq].w, acc[2][bq].w);
+      }
+    }
+    float4* out = dG + (((int64_t)b * h + yq) * w + xq) * 9 * CG + cg;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int bq = 0; bq < 3; ++bq) out[(a * 3 + bq) * CG] = acc[a][bq];
+  }
+}
+
 // out = gate > 0 ? g * scale[c] : 0   (backward of y = relu(scale * z + shift) w.r.t. z, NHWC dense)
 __global__ __launch_bounds__(256) void gate_scale_kernel(const float4* __restrict__ g, const float4* __restrict__ gate,
                                                          const float4* __restrict__ scale, float4* __restrict__ out, int CG,
@@ -177,9 +272,22 @@ extern "C" int sea_tap_gather_fwd(const float* G, float* extra, int accumulate, 
   SEA_CHECK_ARG(((((uintptr_t)G) | ((uintptr_t)extra)) & 15) == 0);
   const int nBh = (H + kTB - 1) / kTB, nBw = (W + kTB - 1) / kTB;
   const int64_t total = (int64_t)B * nBh * nBw * (C / 4);
-  hipLaunchKernelGGL(tap_gather_fwd_kernel, dim3(grid_for_xcd(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const float4*)G, (float4*)extra, accumulate, C / 4, h, w, H, W, (float)h / (float)H,
-                     (float)w / (float)W, nBh, nBw, total, xcd_order_enabled(), divs3(C / 4, nBw, nBh));
+  // the kernel indexes inside one image with 32-bit offsets
+  SEA_CHECK_ARG((int64_t)H * W * (C / 4) < (1ll << 31) && (int64_t)h * w * 9 * (C / 4) < (1ll << 31));
+  const char* ge = getenv("SEA_UPSAMPLE_GENERAL");
+  const bool general_only = ge && ge[0] == '1';
+#define SEA_LAUNCH_TAP_FWD(SS)                                                                                          \
+  hipLaunchKernelGGL(tap_gather_fwd_kernel<SS>, dim3(grid_for_xcd(total, 256)), dim3(256), 0, (hipStream_t)stream,      \
+                     (const float4*)G, (float4*)extra, accumulate, C / 4, h, w, H, W, (float)h / (float)H,              \
+                     (float)w / (float)W, nBh, nBw, total, xcd_order_enabled(), divs3(C / 4, nBw, nBh))
+  if (!general_only && (int64_t)h * 4 == H && (int64_t)w * 4 == W) {
+    SEA_LAUNCH_TAP_FWD(4);
+  } else if (!general_only && (int64_t)h * 8 == H && (int64_t)w * 8 == W) {
+    SEA_LAUNCH_TAP_FWD(8);
+  } else {
+    SEA_LAUNCH_TAP_FWD(0);
+  }
+#undef SEA_LAUNCH_TAP_FWD
   SEA_RETURN_LAST();
 }
 
@@ -188,6 +296,20 @@ extern "C" int sea_tap_gather_bwd(const float* gz, float* dG, int B, int C, int 
   SEA_CHECK_ARG(gz && dG && B > 0 && C > 0 && (C % 4) == 0 && h > 0 && w > 0 && H >= h && W >= w);
   SEA_CHECK_ARG(((((uintptr_t)gz) | ((uintptr_t)dG)) & 15) == 0);
   const int64_t total = (int64_t)B * h * w * (C / 4);
+  static const int general_only = [] {
+    const char* e = getenv("SEA_UPSAMPLE_GENERAL");
+    return (e && e[0] == '1') ? 1 : 0;
+  }();
+  if (!general_only && (int64_t)h * 4 == H && (int64_t)w * 4 == W) {
+    hipLaunchKernelGGL(tap_gather_bwd_pow2_kernel<4>, dim3(grid_for_xcd(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)gz, (float4*)dG, C / 4, h, w, total, xcd_order_enabled(), divs3(C / 4, w, h));
+    SEA_RETURN_LAST();
+  }
+  if (!general_only && (int64_t)h * 8 == H && (int64_t)w * 8 == W) {
+    hipLaunchKernelGGL(tap_gather_bwd_pow2_kernel<8>, dim3(grid_for_xcd(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)gz, (float4*)dG, C / 4, h, w, total, xcd_order_enabled(), divs3(C / 4, w, h));
+    SEA_RETURN_LAST();
+  }
   hipLaunchKernelGGL(tap_gather_bwd_kernel, dim3(grid_for_xcd(total, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const float4*)gz, (float4*)dG, C / 4, h, w, H, W, (float)h / (float)H, (float)w / (float)W, total,
                      xcd_order_enabled(), divs3(C / 4, w, h));

@@ -234,6 +234,73 @@ __global__ __launch_bounds__(256) void upsample_fwd_pow2_kernel(const float* __r
   }
 }
 
+// Cell variant of the forward (the default): one lane = one float4 column of one "cell row" c in [-1, h-1], i.e. the S
+// output rows Y = S*c + S/2 + k that interpolate between input rows c and c+1 (c = -1 / h-1: the clamped half cells).
+// The <= 8 source values and the 8 horizontal interpolants are computed once and feed S float4 stores (x4: 2 loads per
+// store instead of 8, x16: 0.25 instead of 4); every store instruction is still a coalesced row segment.  Same
+// expression tree as upsample_fwd_kernel: identical values.
+template <int S>
+__device__ __forceinline__ void upsample_fwd_cell_item(const float* __restrict__ x, float* __restrict__ y, int h, int w,
+                                                       int x4, int c, int64_t plane) {
+  constexpr int LOG = Pow2<S>::LOG;
+  constexpr int G = (S / 2 >= 4) ? 4 : S / 2;
+  constexpr float inv = 1.f / (float)S;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int H = h * S, W = w * S;
+  const int r0i = c < 0 ? 0 : c, r1i = min(r0i + 1, h - 1);
+  const float* r0 = x + (plane * h + r0i) * w;
+  const float* r1 = x + (plane * h + r1i) * w;
+  float top[4], bot[4];
+#pragma unroll
+  for (int g = 0; g < 4 / G; ++g) {
+    const int tx = x4 * 4 + g * G + S / 2;
+    int c0 = (tx >> LOG) - 1;
+    const bool clamped = c0 < 0;
+    c0 = clamped ? 0 : c0;
+    const int c1 = min(c0 + 1, w - 1);
+    const float a0 = r0[c0], a1 = r0[c1], b0 = r1[c0], b1 = r1[c1];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const float lx = clamped ? 0.f : ((float)((tx + j) & (S - 1)) + 0.5f) * inv;
+      top[g * G + j] = (1.f - lx) * a0 + lx * a1;
+      bot[g * G + j] = (1.f - lx) * b0 + lx * b1;
+    }
+  }
+  float* yp = y + plane * H * W + x4 * 4;
+#pragma unroll
+  for (int k = 0; k < S; ++k) {
+    const int Y = S * c + S / 2 + k;
+    if (Y < 0 || Y >= H) continue;
+    const float ly = c < 0 ? 0.f : ((float)k + 0.5f) * inv;
+    f4 o;
+    o.x = (1.f - ly) * top[0] + ly * bot[0];
+    o.y = (1.f - ly) * top[1] + ly * bot[1];
+    o.z = (1.f - ly) * top[2] + ly * bot[2];
+    o.w = (1.f - ly) * top[3] + ly * bot[3];
+    __builtin_nontemporal_store(o, reinterpret_cast<f4*>(yp + (int64_t)Y * W));
+  }
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void upsample_fwd_cells_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                 int h, int w, int64_t total, int xcd, FastDiv fW4,
+                                                                 FastDiv fC) {
+  const int W4 = (w * S) >> 2, NC = h + 1;
+  const IndexRange rg = xcd_range(total, xcd);
+  if (total < kFastIndexLimit) {
+    const uint32_t end = (uint32_t)rg.end, stride = (uint32_t)rg.stride;
+    for (uint32_t i = (uint32_t)rg.begin; i < end; i += stride) {
+      const uint32_t r = fdiv(i, fW4), plane = fdiv(r, fC);
+      upsample_fwd_cell_item<S>(x, y, h, w, (int)(i - r * W4), (int)(r - plane * NC) - 1, plane);
+    }
+  } else {
+    for (int64_t i = rg.begin; i < rg.end; i += rg.stride) {
+      const int64_t r = i / W4;
+      upsample_fwd_cell_item<S>(x, y, h, w, (int)(i % W4), (int)(r % NC) - 1, r / NC);
+    }
+  }
+}
+
 // Gather, deterministic: one lane = one INPUT pixel; its footprint is the 2S x 2S output window starting at
 // (S*yq - S/2, S*xq - S/2) with the separable weights c[t] = (t+0.5)/S (t < S: the pixel is the right/bottom neighbour
 // i1) and (2S-t-0.5)/S (t >= S: it is i0).  Edges: window parts outside the image are skipped; where the source index
@@ -403,6 +470,27 @@ static inline int upsample_general_only() {
 // Lanes run along the channel dimension (16-byte accesses, perfectly coalesced); no LDS.  The UperNet head
 // is channels_last end to end on ROCm (MIOpen's NHWC igemm kernels return that layout), so these variants
 // remove the layout copies around every up-sampling.
+// S > 0: power-of-two factor in both axes, integer source map (identical values, no float index arithmetic)
+template <int S>
+__device__ __forceinline__ AxisMapU nhwc_axis(int dst, float r, int n_in) {
+  if constexpr (S == 0) {
+    return axis_map_u(dst, r, n_in);
+  } else {
+    constexpr int LOG = Pow2<S>::LOG;
+    const int t = dst + S / 2;
+    AxisMapU m;
+    m.i0 = (t >> LOG) - 1;
+    m.lam = ((float)(t & (S - 1)) + 0.5f) * (1.f / (float)S);
+    if (m.i0 < 0) {
+      m.i0 = 0;
+      m.lam = 0.f;
+    }
+    m.i1 = min(m.i0 + 1, n_in - 1);
+    return m;
+  }
+}
+
+template <int S>
 __global__ __launch_bounds__(256) void upsample_nhwc_fwd_kernel(const float4* __restrict__ x,
                                                                 const float4* __restrict__ res, float4* __restrict__ y,
                                                                 int CG, int h, int w, int H, int W, float rh, float rw,
@@ -414,7 +502,7 @@ __global__ __launch_bounds__(256) void upsample_nhwc_fwd_kernel(const float4* __
     const int cg = ix.c0, X = ix.c1, Y = ix.c2;
     const int b = (int)ix.c3;
     const int64_t opix = ((int64_t)b * H + Y) * W + X;
-    const AxisMapU my = axis_map_u(Y, rh, h), mx = axis_map_u(X, rw, w);
+    const AxisMapU my = nhwc_axis<S>(Y, rh, h), mx = nhwc_axis<S>(X, rw, w);
     const float4* xb = x + (int64_t)b * h * w * CG + cg;
     const float4 v00 = xb[((int64_t)my.i0 * w + mx.i0) * CG], v01 = xb[((int64_t)my.i0 * w + mx.i1) * CG];
     const float4 v10 = xb[((int64_t)my.i1 * w + mx.i0) * CG], v11 = xb[((int64_t)my.i1 * w + mx.i1) * CG];
@@ -432,6 +520,62 @@ __global__ __launch_bounds__(256) void upsample_nhwc_fwd_kernel(const float4* __
       o.w += r.w;
     }
     y[opix * ypg + cg] = o;
+  }
+}
+
+// Cell variant for power-of-two factors (the default there): one lane = 4 channels of one cell (cy, cx) in
+// [-1, h-1] x [-1, w-1]: the S x S output pixels that interpolate between the same four source pixels.  4 loads and 2S
+// horizontal interpolants feed up to S*S coalesced 16-byte stores (the per-pixel kernel spends 4 loads and a full index
+// decomposition per store).  Same expression tree: identical values.
+template <int S>
+__global__ __launch_bounds__(256) void upsample_nhwc_fwd_cells_kernel(const float4* __restrict__ x,
+                                                                      const float4* __restrict__ res,
+                                                                      float4* __restrict__ y, int CG, int h, int w,
+                                                                      int64_t total, int64_t ypg, int xcd, Divs3 dv) {
+  constexpr float inv = 1.f / (float)S;
+  const int H = h * S, W = w * S;
+  const IndexRange rg = xcd_range(total, xcd);
+  const bool fast = total < kFastIndexLimit;
+  for (int64_t i = rg.begin; i < rg.end; i += rg.stride) {
+    const Index4 ix = split_index(i, dv, fast);  // (cg, cx + 1, cy + 1, b)
+    const int cg = ix.c0, cx = ix.c1 - 1, cy = ix.c2 - 1;
+    const int b = (int)ix.c3;
+    const int r0 = cy < 0 ? 0 : cy, r1 = min(r0 + 1, h - 1), c0 = cx < 0 ? 0 : cx, c1 = min(c0 + 1, w - 1);
+    const float4* xb = x + (int64_t)b * h * w * CG + cg;
+    const float4 v00 = xb[((int64_t)r0 * w + c0) * CG], v01 = xb[((int64_t)r0 * w + c1) * CG];
+    const float4 v10 = xb[((int64_t)r1 * w + c0) * CG], v11 = xb[((int64_t)r1 * w + c1) * CG];
+    float4 t0[S], t1[S];
+#pragma unroll
+    for (int kx = 0; kx < S; ++kx) {
+      const float lx = cx < 0 ? 0.f : ((float)kx + 0.5f) * inv, ux = 1.f - lx;
+      t0[kx] = make_float4(ux * v00.x + lx * v01.x, ux * v00.y + lx * v01.y, ux * v00.z + lx * v01.z,
+                           ux * v00.w + lx * v01.w);
+      t1[kx] = make_float4(ux * v10.x + lx * v11.x, ux * v10.y + lx * v11.y, ux * v10.z + lx * v11.z,
+                           ux * v10.w + lx * v11.w);
+    }
+    const int Yb = S * cy + S / 2, Xb = S * cx + S / 2;
+#pragma unroll
+    for (int ky = 0; ky < S; ++ky) {
+      const int Y = Yb + ky;
+      if (Y < 0 || Y >= H) continue;
+      const float ly = cy < 0 ? 0.f : ((float)ky + 0.5f) * inv, uy = 1.f - ly;
+#pragma unroll
+      for (int kx = 0; kx < S; ++kx) {
+        const int X = Xb + kx;
+        if (X < 0 || X >= W) continue;
+        const int64_t opix = ((int64_t)b * H + Y) * W + X;
+        float4 o = make_float4(uy * t0[kx].x + ly * t1[kx].x, uy * t0[kx].y + ly * t1[kx].y,
+                               uy * t0[kx].z + ly * t1[kx].z, uy * t0[kx].w + ly * t1[kx].w);
+        if (res) {
+          const float4 r = res[opix * CG + cg];
+          o.x += r.x;
+          o.y += r.y;
+          o.z += r.z;
+          o.w += r.w;
+        }
+        y[opix * ypg + cg] = o;
+      }
+    }
   }
 }
 
@@ -472,6 +616,59 @@ __global__ __launch_bounds__(256) void upsample_nhwc_bwd_kernel(const float4* __
   }
 }
 
+// Power-of-two factor: the footprint of input pixel (yq, xq) is the 2S x 2S window at (S*yq - S/2, S*xq - S/2) with the
+// separable constant weights of upsample_bwd_pow2_kernel; the rows are unrolled (2S independent 16-byte loads in flight
+// per lane instead of one dependent load per tap), no float index arithmetic.
+template <int S>
+__global__ __launch_bounds__(256) void upsample_nhwc_bwd_pow2_kernel(const float4* __restrict__ gy,
+                                                                     float4* __restrict__ gx, int CG, int h, int w,
+                                                                     int64_t total, int64_t gpg, int xcd, Divs3 dv) {
+  constexpr int T = 2 * S;
+  constexpr float inv = 1.f / (float)S;
+  const int H = h * S, W = w * S;
+  const IndexRange rg = xcd_range(total, xcd);
+  const bool fast = total < kFastIndexLimit;
+  for (int64_t i = rg.begin; i < rg.end; i += rg.stride) {
+    const Index4 ix = split_index(i, dv, fast);  // (cg, xq, yq, b)
+    const int cg = ix.c0, xq = ix.c1, yq = ix.c2;
+    const int b = (int)ix.c3;
+    const bool eL = xq == 0, eR = xq == w - 1, eT = yq == 0, eB = yq == h - 1;
+    const int X0 = S * xq - S / 2, Y0 = S * yq - S / 2;
+    const float4* gb = gy + ((int64_t)b * H * W + X0) * gpg + cg;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 2
+    for (int ty = 0; ty < T; ++ty) {
+      const int Y = Y0 + ty;
+      if (Y < 0 || Y >= H) continue;
+      float cy = (ty < S) ? ((float)ty + 0.5f) * inv : ((float)(2 * S - ty) - 0.5f) * inv;
+      cy = ((eT && ty < S) || (eB && ty >= S)) ? 1.f : cy;
+      const float4* row = gb + (int64_t)Y * W * gpg;
+      float4 v[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const bool outside = (eL && t < S / 2) || (eR && t >= 3 * S / 2);
+        v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!outside) v[t] = row[(int64_t)t * gpg];
+      }
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const float c = (t < S) ? ((float)t + 0.5f) * inv : ((float)(2 * S - t) - 0.5f) * inv;
+        const float wx = ((eL && t < S) || (eR && t >= S)) ? 1.f : c;
+        r.x = fmaf(wx, v[t].x, r.x);
+        r.y = fmaf(wx, v[t].y, r.y);
+        r.z = fmaf(wx, v[t].z, r.z);
+        r.w = fmaf(wx, v[t].w, r.w);
+      }
+      acc.x = fmaf(cy, r.x, acc.x);
+      acc.y = fmaf(cy, r.y, acc.y);
+      acc.z = fmaf(cy, r.z, acc.z);
+      acc.w = fmaf(cy, r.w, acc.w);
+    }
+    gx[i] = acc;
+  }
+}
+
 static bool plan_bwd(int h, int w, int H, int W, int* TI, int* RMAX, size_t* lds) {
   const double sh = (double)H / h, sw = (double)W / w;
   const double s = sh > sw ? sh : sw;
@@ -503,6 +700,22 @@ extern "C" int sea_upsample_bilinear_fwd(const float* x, float* y, int64_t plane
   const int S = upsample_general_only() ? 0 : pow2_factor(h, w, H, W);
   if (S && (((uintptr_t)y) & 15) == 0) {  // float4 stores: W % 4 == 0 and a 16-byte aligned base
     if ((W & 3) == 0) {
+      static const int lanes_only = [] {
+        const char* e = getenv("SEA_UPSAMPLE_FWD");
+        return (e && e[0] == 'l') ? 1 : 0;  // "lane": one float4 per lane (A/B against the cell variant)
+      }();
+      if (S >= 4 && !lanes_only) {
+        const int64_t total = planes * (h + 1) * (W / 4);
+        const dim3 grid(grid_for_xcd(total, 256)), block(256);
+        const int xo = xcd_order_enabled() == 2;
+        const FastDiv fW4 = fast_div((uint32_t)(W / 4)), fC = fast_div((uint32_t)(h + 1));
+        switch (S) {
+          case 4: hipLaunchKernelGGL(upsample_fwd_cells_kernel<4>, grid, block, 0, s, x, y, h, w, total, xo, fW4, fC); break;
+          case 8: hipLaunchKernelGGL(upsample_fwd_cells_kernel<8>, grid, block, 0, s, x, y, h, w, total, xo, fW4, fC); break;
+          default: hipLaunchKernelGGL(upsample_fwd_cells_kernel<16>, grid, block, 0, s, x, y, h, w, total, xo, fW4, fC); break;
+        }
+        SEA_RETURN_LAST();
+      }
       const int64_t total = planes * H * (W / 4);
       const dim3 grid(grid_for_xcd(total, 256)), block(256);
       // a pure output stream (the input is S^2 times smaller): the plain block order measured 10 % faster than the
@@ -599,9 +812,40 @@ extern "C" int sea_upsample_bilinear_nhwc_fwd(const float* x, const float* resid
   SEA_CHECK_ARG(y_pixel_stride >= C && (y_pixel_stride % 4) == 0);
   SEA_CHECK_ARG(((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)residual)) & 15) == 0);
   const int64_t total = (int64_t)B * H * W * (C / 4);
-  hipLaunchKernelGGL(upsample_nhwc_fwd_kernel, dim3(grid_for_xcd(total, 256 * 2)), dim3(256), 0, (hipStream_t)stream,
-                     (const float4*)x, (const float4*)residual, (float4*)y, C / 4, h, w, H, W, (float)h / (float)H, (float)w / (float)W, total,
-                     y_pixel_stride / 4, xcd_order_enabled(), divs3(C / 4, W, H));
+  const int S = upsample_general_only() ? 0 : pow2_factor(h, w, H, W);
+#define SEA_LAUNCH_NHWC_FWD(SS)                                                                                         \
+  hipLaunchKernelGGL(upsample_nhwc_fwd_kernel<SS>, dim3(grid_for_xcd(total, 256 * 2)), dim3(256), 0,                   \
+                     (hipStream_t)stream, (const float4*)x, (const float4*)residual, (float4*)y, C / 4, h, w, H, W,     \
+                     (float)h / (float)H, (float)w / (float)W, total, y_pixel_stride / 4, xcd_order_enabled(),          \
+                     divs3(C / 4, W, H))
+  static const int lanes_only = [] {
+    const char* e = getenv("SEA_UPSAMPLE_FWD");
+    return (e && e[0] == 'l') ? 1 : 0;
+  }();
+  if ((S == 2 || S == 4 || S == 8) && !lanes_only) {
+    const int64_t cells = (int64_t)B * (h + 1) * (w + 1) * (C / 4);
+#define SEA_LAUNCH_NHWC_FWD_CELLS(SS)                                                                                   \
+  hipLaunchKernelGGL(upsample_nhwc_fwd_cells_kernel<SS>, dim3(grid_for_xcd(cells, 256)), dim3(256), 0,                  \
+                     (hipStream_t)stream, (const float4*)x, (const float4*)residual, (float4*)y, C / 4, h, w, cells,    \
+                     y_pixel_stride / 4, xcd_order_enabled(), divs3(C / 4, w + 1, h + 1))
+    if (S == 2) {
+      SEA_LAUNCH_NHWC_FWD_CELLS(2);
+    } else if (S == 4) {
+      SEA_LAUNCH_NHWC_FWD_CELLS(4);
+    } else {
+      SEA_LAUNCH_NHWC_FWD_CELLS(8);
+    }
+#undef SEA_LAUNCH_NHWC_FWD_CELLS
+    SEA_RETURN_LAST();
+  }
+  switch (S) {
+    case 2: SEA_LAUNCH_NHWC_FWD(2); break;
+    case 4: SEA_LAUNCH_NHWC_FWD(4); break;
+    case 8: SEA_LAUNCH_NHWC_FWD(8); break;
+    case 16: SEA_LAUNCH_NHWC_FWD(16); break;
+    default: SEA_LAUNCH_NHWC_FWD(0); break;
+  }
+#undef SEA_LAUNCH_NHWC_FWD
   SEA_RETURN_LAST();
 }
 
@@ -611,8 +855,22 @@ extern "C" int sea_upsample_bilinear_nhwc_bwd(const float* gy, float* gx, int B,
   SEA_CHECK_ARG(gy_pixel_stride >= C && (gy_pixel_stride % 4) == 0);
   SEA_CHECK_ARG(((((uintptr_t)gy) | ((uintptr_t)gx)) & 15) == 0);
   const int64_t total = (int64_t)B * h * w * (C / 4);
-  hipLaunchKernelGGL(upsample_nhwc_bwd_kernel, dim3(grid_for_xcd(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const float4*)gy, (float4*)gx, C / 4, h, w, H, W, (float)h / (float)H, (float)w / (float)W, total,
-                     gy_pixel_stride / 4, xcd_order_enabled(), divs3(C / 4, w, h));
+  const int S = upsample_general_only() ? 0 : pow2_factor(h, w, H, W);
+#define SEA_LAUNCH_NHWC_BWD(SS)                                                                                         \
+  hipLaunchKernelGGL(upsample_nhwc_bwd_pow2_kernel<SS>, dim3(grid_for_xcd(total, 256)), dim3(256), 0,                   \
+                     (hipStream_t)stream, (const float4*)gy, (float4*)gx, C / 4, h, w, total, gy_pixel_stride / 4,     \
+                     xcd_order_enabled(), divs3(C / 4, w, h))
+  if (S == 2) {
+    SEA_LAUNCH_NHWC_BWD(2);
+  } else if (S == 4) {
+    SEA_LAUNCH_NHWC_BWD(4);
+  } else if (S == 8) {
+    SEA_LAUNCH_NHWC_BWD(8);
+  } else {
+    hipLaunchKernelGGL(upsample_nhwc_bwd_kernel, dim3(grid_for_xcd(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)gy, (float4*)gx, C / 4, h, w, H, W, (float)h / (float)H, (float)w / (float)W,
+                       total, gy_pixel_stride / 4, xcd_order_enabled(), divs3(C / 4, w, h));
+  }
+#undef SEA_LAUNCH_NHWC_BWD
   SEA_RETURN_LAST();
 }

@@ -431,7 +431,9 @@ def test_upsample_bilinear_forward_backward(N, case):
 @pytest.mark.parametrize("case", [(2, 8, 16, 16, 32, 32), (1, 4, 32, 32, 128, 128), (2, 12, 16, 16, 128, 128),
                                   (1, 4, 1, 1, 16, 16), (1, 8, 3, 3, 16, 16), (2, 4, 6, 6, 16, 16),
                                   (1, 8, 30, 30, 119, 119), (1, 4, 13, 11, 50, 45), (1, 4, 9, 7, 9, 7),
-                                  (2, 512, 4, 4, 8, 8)])
+                                  (2, 512, 4, 4, 8, 8),
+                                  # power-of-two factors with edges everywhere (specialised NHWC kernels)
+                                  (1, 4, 2, 3, 8, 12), (1, 8, 3, 2, 24, 16), (1, 4, 5, 1, 10, 2), (1, 4, 1, 5, 4, 20)])
 def test_upsample_bilinear_channels_last(N, case):
     """The NHWC kernels must agree with the NCHW ones (same arithmetic) and with ATen."""
     import torch.nn.functional as F
@@ -524,7 +526,8 @@ def test_upernet_head_with_and_without_hip_upsample(N):
 
 # ------------------------------------------------------------------------------------------------ M6
 @pytest.mark.parametrize("case", [(2, 8, 12, 4, 4, 16, 16), (1, 16, 8, 3, 5, 24, 40), (2, 4, 4, 1, 1, 8, 8),
-                                  (1, 8, 8, 5, 4, 17, 13), (1, 32, 64, 8, 8, 64, 64)])
+                                  (1, 8, 8, 5, 4, 17, 13), (1, 32, 64, 8, 8, 64, 64), (1, 8, 8, 2, 6, 8, 24),
+                                  (2, 4, 8, 7, 1, 28, 4)])
 def test_tap_gather_is_conv3x3_of_the_upsampled_input(N, case):
     """conv3x3(up(f)) == tap_gather(f @ W) (channel mixing commutes with bilinear interpolation), and the
     backward kernel is the exact adjoint."""

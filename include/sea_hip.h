@@ -214,6 +214,11 @@ int sea_dwconv7x7(const float* x, const float* w, const float* bias, float* y, i
  * With it the whole ConvNeXt block runs in NHWC: no permute / layout copy is left. */
 int sea_dwconv7x7_nhwc(const float* x, const float* wt, const float* bias, float* y, int B, int C,
                        int H, int W, int flip, void* stream);
+/* same, plus an optional addend of y's shape: y = conv(x) + addend (added after the taps: bitwise what a separate
+ * element-wise add gives).  The backward of a ConvNeXt block (x + branch(x), convnext_orig.py:75-86) passes the skip
+ * gradient here, which removes one element-wise pass per block.  bias and addend are mutually exclusive. */
+int sea_dwconv7x7_nhwc_add(const float* x, const float* wt, const float* bias, const float* addend, float* y, int B,
+                           int C, int H, int W, int flip, void* stream);
 
 /* M2  (model side) bilinear up-sampling, align_corners=False, fp32 NCHW planes: forward and its
  * backward w.r.t. the input (gather formulation, deterministic; ATen scatters with atomics).

@@ -83,14 +83,17 @@ __global__ __launch_bounds__(256) void dwconv7x7_kernel(const float* __restrict_
 // pointwise MLP consume the NHWC result as is.
 constexpr int DWN_STRIP = 8;
 
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
 //
 // Block order: a 1-D grid whose linear id is dealt round-robin to the 8 XCDs by the hardware.  Seven output rows read
 // the same input row, so neighbouring rows must meet in the SAME L2: block `id` works on unit (id % 8) * per_xcd + id / 8
 // of the (image, row, strip group) linearisation, i.e. every XCD sweeps its own contiguous band of rows (one image per
 // XCD at B = 8) and fetches it from the fabric once instead of all eight XCDs fetching everything.
-template <bool FLIP, bool BIAS>
+template <bool FLIP, bool BIAS, bool ADD>
 __global__ __launch_bounds__(256) void dwconv7x7_nhwc_kernel(const float4* __restrict__ x, const float4* __restrict__ wt,
-                                                             const float4* __restrict__ bias, float4* __restrict__ y,
+                                                             const float4* __restrict__ bias,
+                                                             const float4* __restrict__ addend, float4* __restrict__ y,
                                                              int CG, int H, int W, int strips_per_block, int gx, int units,
                                                              int per_xcd) {
   const int cg = threadIdx.x % CG, ps = threadIdx.x / CG;
@@ -129,42 +132,163 @@ __global__ __launch_bounds__(256) void dwconv7x7_nhwc_kernel(const float4* __res
       }
     }
   }
-  float4* yr = y + ((int64_t)b * H + oy) * W * CG + cg;
+  const int64_t ro = ((int64_t)b * H + oy) * W * CG + cg;
+  float4* yr = y + ro;
 #pragma unroll
   for (int j = 0; j < DWN_STRIP; ++j)
-    if (ox0 + j < W) yr[(int64_t)(ox0 + j) * CG] = acc[j];
+    if (ox0 + j < W) {
+      if (ADD) acc[j] = add4(acc[j], addend[ro + (int64_t)(ox0 + j) * CG]);  // y = conv + addend (added last)
+      yr[(int64_t)(ox0 + j) * CG] = acc[j];
+    }
+}
+
+// Two output rows per lane: input row r feeds output row oy0 with filter row ky = r and output row oy0 + 1 with
+// ky = r - 1, so every input row (14 loads) is loaded once for both: 210 loads per 16
+// output float4 instead of 294 (the single-row kernel is bound by the L1 issue rate: 18 loads per output).
+// Accumulation order per output is unchanged (bias, then ky ascending, kx ascending): identical bits.
+template <bool FLIP, bool BIAS, bool ADD>
+__global__ __launch_bounds__(256, 2) void dwconv7x7_nhwc_2row_kernel(const float4* __restrict__ x,
+                                                                     const float4* __restrict__ wt,
+                                                                     const float4* __restrict__ bias,
+                                                                     const float4* __restrict__ addend,
+                                                                     float4* __restrict__ y, int CG, int H, int W,
+                                                                     int strips_per_block, int gx, int HP, int units,
+                                                                     int per_xcd) {
+  const int cg = threadIdx.x % CG, ps = threadIdx.x / CG;
+  if (ps >= strips_per_block) return;
+  const int u = per_xcd ? (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  if (u >= units) return;
+  const int bx = u % gx, op = (u / gx) % HP, b = u / (gx * HP);
+  const int oy0 = op * 2;
+  const int ox0 = (bx * strips_per_block + ps) * DWN_STRIP;
+  if (ox0 >= W) return;
+  float4 acc0[DWN_STRIP], acc1[DWN_STRIP];
+  const float4 b0 = BIAS ? bias[cg] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < DWN_STRIP; ++j) acc0[j] = acc1[j] = b0;
+  const float4* xb = x + (int64_t)b * H * W * CG + cg;
+  const float4* wb = wt + cg;
+
+  auto load_filter_row = [&](int ky, float4* w) {
+#pragma unroll
+    for (int kx = 0; kx < DW_K; ++kx) {
+      const int tap = ky * DW_K + kx;
+      w[kx] = wb[(FLIP ? (DW_K * DW_K - 1 - tap) : tap) * CG];
+    }
+  };
+  auto load_input_row = [&](int iy, float4* in) {
+    const bool row_ok = iy >= 0 && iy < H;
+    const float4* row = xb + (int64_t)(row_ok ? iy : 0) * W * CG;
+#pragma unroll
+    for (int j = 0; j < DWN_STRIP + DW_K - 1; ++j) {
+      const int ixp = ox0 + j - DW_P;
+      in[j] = (row_ok && ixp >= 0 && ixp < W) ? row[(int64_t)ixp * CG] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto accumulate = [&](const float4* in, const float4* w, float4* acc) {
+#pragma unroll
+    for (int kx = 0; kx < DW_K; ++kx)
+#pragma unroll
+      for (int j = 0; j < DWN_STRIP; ++j) {
+        acc[j].x = fmaf(in[j + kx].x, w[kx].x, acc[j].x);
+        acc[j].y = fmaf(in[j + kx].y, w[kx].y, acc[j].y);
+        acc[j].z = fmaf(in[j + kx].z, w[kx].z, acc[j].z);
+        acc[j].w = fmaf(in[j + kx].w, w[kx].w, acc[j].w);
+      }
+  };
+  // r = 0 .. 7: input row oy0 - 3 + r; rows outside the image contribute zeros (and are not loaded).  One filter row
+  // is live at a time (holding both rows of a step costs 28 more registers than the 256 budget of 2 waves/SIMD allows;
+  // the second load of a filter row is an L1 hit).
+#pragma unroll 1
+  for (int r = 0; r < DW_K + 1; ++r) {
+    float4 in[DWN_STRIP + DW_K - 1];
+    float4 w[DW_K];
+    load_input_row(oy0 - DW_P + r, in);
+    if (r < DW_K) {
+      load_filter_row(r, w);
+      accumulate(in, w, acc0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (r >= 1) {
+      load_filter_row(r - 1, w);
+      accumulate(in, w, acc1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const int64_t ro = ((int64_t)b * H + oy0) * W * CG + cg;
+  float4* yr = y + ro;
+#pragma unroll
+  for (int j = 0; j < DWN_STRIP; ++j)
+    if (ox0 + j < W) {
+      if (ADD) acc0[j] = add4(acc0[j], addend[ro + (int64_t)(ox0 + j) * CG]);  // y = conv + addend (added last)
+      yr[(int64_t)(ox0 + j) * CG] = acc0[j];
+    }
+  if (oy0 + 1 < H) {
+#pragma unroll
+    for (int j = 0; j < DWN_STRIP; ++j)
+      if (ox0 + j < W) {
+        if (ADD) acc1[j] = add4(acc1[j], addend[ro + ((int64_t)W + ox0 + j) * CG]);
+        yr[((int64_t)W + ox0 + j) * CG] = acc1[j];
+      }
+  }
 }
 
 }  // namespace sea
 
 using namespace sea;
 
-// x, y: (B,H,W,C) contiguous fp32, C % 4 == 0, C <= 1024; wt: (49, C) taps-major; bias (C) or NULL.
-extern "C" int sea_dwconv7x7_nhwc(const float* x, const float* wt, const float* bias, float* y, int B, int C, int H,
-                                  int W, int flip, void* stream) {
+// x, y: (B,H,W,C) contiguous fp32, C % 4 == 0, C <= 1024; wt: (49, C) taps-major; bias (C) or NULL; addend (same
+// shape as y) or NULL: y = conv(x) + addend, added after the taps (bitwise what a separate element-wise add gives; the
+// backward of a residual block hands the skip gradient in here).
+extern "C" int sea_dwconv7x7_nhwc_add(const float* x, const float* wt, const float* bias, const float* addend, float* y,
+                                      int B, int C, int H, int W, int flip, void* stream) {
   SEA_CHECK_ARG(x && wt && y && B > 0 && B <= 65535 && C > 0 && (C % 4) == 0 && C <= 1024 && H > 0 && H <= 65535 && W > 0);
-  SEA_CHECK_ARG(((((uintptr_t)x) | ((uintptr_t)wt) | ((uintptr_t)y) | ((uintptr_t)bias)) & 15) == 0);
+  SEA_CHECK_ARG(((((uintptr_t)x) | ((uintptr_t)wt) | ((uintptr_t)y) | ((uintptr_t)bias) | ((uintptr_t)addend)) & 15) == 0);
+  SEA_CHECK_ARG(!(addend && bias));  // forward: bias; backward-data: addend
   const int CG = C / 4;
   const int spb = 256 / CG;  // strips per block (>= 1 because CG <= 256)
   const int strips = (W + DWN_STRIP - 1) / DWN_STRIP;
   const int gx = (strips + spb - 1) / spb;
-  const int64_t units64 = (int64_t)gx * H * B;
+  hipStream_t s = (hipStream_t)stream;
+  const float4 *x4 = (const float4*)x, *w4 = (const float4*)wt, *b4 = (const float4*)bias, *a4 = (const float4*)addend;
+  float4* y4 = (float4*)y;
+  // flip bit 1 (value 2): plain linear block order; bit 2 (value 4): one output row per lane (A/B switches for
+  // tools/dev/dwconv_bench.py)
+  const bool two_rows = !(flip & 4) && H >= 2;
+  const int HP = two_rows ? (H + 1) / 2 : H;
+  const int64_t units64 = (int64_t)gx * HP * B;
   SEA_CHECK_ARG(units64 < (1ll << 30));
   const int units = (int)units64;
-  // flip bit 1 (value 2): plain linear block order (A/B switch for tools/dev/dwconv_bench.py)
   const int per_xcd = (flip & 2) ? 0 : (units + 7) / 8;
   dim3 grid(per_xcd ? per_xcd * 8 : units), block(256);
-  hipStream_t s = (hipStream_t)stream;
-  if (flip & 1)
-    hipLaunchKernelGGL((dwconv7x7_nhwc_kernel<true, false>), grid, block, 0, s, (const float4*)x, (const float4*)wt,
-                       (const float4*)nullptr, (float4*)y, CG, H, W, spb, gx, units, per_xcd);
-  else if (bias)
-    hipLaunchKernelGGL((dwconv7x7_nhwc_kernel<false, true>), grid, block, 0, s, (const float4*)x, (const float4*)wt,
-                       (const float4*)bias, (float4*)y, CG, H, W, spb, gx, units, per_xcd);
-  else
-    hipLaunchKernelGGL((dwconv7x7_nhwc_kernel<false, false>), grid, block, 0, s, (const float4*)x, (const float4*)wt,
-                       (const float4*)nullptr, (float4*)y, CG, H, W, spb, gx, units, per_xcd);
+#define SEA_DW_LAUNCH(F, BI, AD)                                                                                        \
+  do {                                                                                                                  \
+    if (two_rows)                                                                                                       \
+      hipLaunchKernelGGL((dwconv7x7_nhwc_2row_kernel<F, BI, AD>), grid, block, 0, s, x4, w4, b4, a4, y4, CG, H, W, spb,  \
+                         gx, HP, units, per_xcd);                                                                       \
+    else                                                                                                                \
+      hipLaunchKernelGGL((dwconv7x7_nhwc_kernel<F, BI, AD>), grid, block, 0, s, x4, w4, b4, a4, y4, CG, H, W, spb, gx,   \
+                         units, per_xcd);                                                                               \
+  } while (0)
+  if (flip & 1) {
+    if (addend)
+      SEA_DW_LAUNCH(true, false, true);
+    else
+      SEA_DW_LAUNCH(true, false, false);
+  } else if (bias) {
+    SEA_DW_LAUNCH(false, true, false);
+  } else if (addend) {
+    SEA_DW_LAUNCH(false, false, true);
+  } else {
+    SEA_DW_LAUNCH(false, false, false);
+  }
+#undef SEA_DW_LAUNCH
   SEA_RETURN_LAST();
+}
+
+extern "C" int sea_dwconv7x7_nhwc(const float* x, const float* wt, const float* bias, float* y, int B, int C, int H,
+                                  int W, int flip, void* stream) {
+  return sea_dwconv7x7_nhwc_add(x, wt, bias, nullptr, y, B, C, H, W, flip, stream);
 }
 
 // x, y: (planes = B*C, H, W) contiguous fp32; w: (C,1,7,7); bias: (C) or NULL.

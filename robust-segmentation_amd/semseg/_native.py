@@ -47,6 +47,7 @@ _SIGS = {
     "sea_worst_miou_greedy": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "sea_dwconv7x7": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sea_dwconv7x7_nhwc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sea_dwconv7x7_nhwc_add": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sea_nchw_to_nhwc": (_i, [_vp, _vp, _vp, _i, _i, _i64, _vp]),
     "sea_nhwc_to_nchw": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _vp]),
     "sea_upsample_bilinear_fwd": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp]),
@@ -519,13 +520,16 @@ def wino_conv3x3_cl(x, U, m: int, bias=None, scale=None, relu: bool = False, gat
     return y
 
 
-def dwconv7x7_nhwc(x, wt, bias=None, flip: bool = False):
-    """Depthwise 7x7 on a (B,H,W,C) contiguous tensor; wt is the (49,C) taps-major filter bank."""
-    _dev(x, wt, bias)
+def dwconv7x7_nhwc(x, wt, bias=None, flip: bool = False, addend=None):
+    """Depthwise 7x7 on a (B,H,W,C) contiguous tensor; wt is the (49,C) taps-major filter bank; ``addend`` (shape of
+    the result) is added after the taps (the skip gradient in the backward of a residual block)."""
+    _dev(x, wt, bias, addend)
     B, H, W, Cc = x.shape
+    if addend is not None and (addend.shape != x.shape or addend.dtype != torch.float32 or not addend.is_contiguous()):
+        raise SeaNativeError("dwconv7x7_nhwc: addend must be a contiguous float32 tensor of the input's shape")
     y = torch.empty_like(x)
-    _check(lib().sea_dwconv7x7_nhwc(_p(_f32c(x)), _p(_f32c(wt)), _p(bias), _p(y), B, Cc, H, W, int(flip), _stream()),
-           "sea_dwconv7x7_nhwc")
+    _check(lib().sea_dwconv7x7_nhwc_add(_p(_f32c(x)), _p(_f32c(wt)), _p(bias), _p(addend), _p(y), B, Cc, H, W, int(flip),
+                                        _stream()), "sea_dwconv7x7_nhwc_add")
     return y
 
 

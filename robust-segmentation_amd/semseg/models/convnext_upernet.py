@@ -178,6 +178,43 @@ class _DwConv7x7NHWC(torch.autograd.Function):
         return gx, gw, gb, None
 
 
+class _DwConv7x7NHWCSkip(torch.autograd.Function):
+    """The depthwise layer of a residual block together with the block's skip connection: returns ``(skip, y)`` with
+    ``skip`` an alias of the input.  The block computes ``skip + branch(y)``; in the backward the skip gradient
+    arrives here next to the branch gradient and is added inside the backward-data kernel (``y = conv(g) + g_skip``,
+    added after the taps: bitwise what autograd's separate accumulation kernel would give) instead of in an
+    element-wise pass of its own (reference block: convnext_orig.py:75-86)."""
+
+    @staticmethod
+    @_fp32_fwd
+    def forward(ctx, x, weight, bias, wt):
+        from .. import _native as N
+        ctx.save_for_backward(x, weight, wt)
+        ctx.has_bias = bias is not None
+        return x.view_as(x), N.dwconv7x7_nhwc(x, wt, bias, flip=False)
+
+    @staticmethod
+    @_fp32_bwd
+    def backward(ctx, g_skip, gy):
+        from .. import _native as N
+        x, weight, wt = ctx.saved_tensors
+        gx = gw = gb = None
+        if gy is None:
+            return g_skip, None, None, None
+        gy = gy.contiguous()
+        if ctx.needs_input_grad[0]:
+            add = None
+            if g_skip is not None:
+                add = g_skip if (g_skip.is_contiguous() and g_skip.dtype == torch.float32) else g_skip.float().contiguous()
+            gx = N.dwconv7x7_nhwc(gy, wt, None, flip=True, addend=add)
+        if ctx.needs_input_grad[1]:
+            gw = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2), weight.shape, gy.permute(0, 3, 1, 2), padding=3,
+                                             groups=x.shape[-1])
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum((0, 1, 2))
+        return gx, gw, gb, None
+
+
 def _tkey(*ts):
     """Cache key of weights derived from the tensors ``ts``: object identity, storage address, in-place version and
     device of every source.  The identity term covers a parameter that was REPLACED by a fresh tensor which happens
@@ -295,7 +332,8 @@ class Block(nn.Module):
                 and x.is_contiguous(memory_format=torch.channels_last)):
             # channels_last trunk (what MIOpen's NHWC convolutions hand us): the whole block stays in NHWC
             xn = x.permute(0, 2, 3, 1)  # contiguous (B,H,W,C) view
-            y = _DwConv7x7NHWC.apply(xn, self.dwconv.weight, self.dwconv.bias, _taps_major(self.dwconv))
+            # (skip, y): the skip gradient is added inside the depthwise backward kernel
+            xn, y = _DwConv7x7NHWCSkip.apply(xn, self.dwconv.weight, self.dwconv.bias, _taps_major(self.dwconv))
             y = self.act(self.pwconv1(self.norm(y)))
             w2, b2, g = self.pwconv2.weight, self.pwconv2.bias, self.gamma
             if g is not None and not (w2.requires_grad or g.requires_grad or (b2 is not None and b2.requires_grad)):

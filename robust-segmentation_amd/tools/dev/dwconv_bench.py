@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""M1 (depthwise 7x7, NHWC) A/B: XCD-aware block order vs plain linear order, on the four ConvNeXt-T stage shapes.
+"""M1 (depthwise 7x7, NHWC) A/B: two output rows per lane (default) vs one row, XCD-aware vs plain block order, on the four
+ConvNeXt-T stage shapes.
 
     python robust-segmentation_amd/tools/dev/dwconv_bench.py
 
@@ -44,7 +45,8 @@ def main():
             yb = N.dwconv7x7_nhwc(xs[0], wt, bias, flip=fl | 2)
             same = torch.equal(ya, yb)
             mb = 8 * xs[0].numel() / 1e6
-            for order, f in (("xcd", fl), ("linear", fl | 2)):
+            same = same and torch.equal(ya, N.dwconv7x7_nhwc(xs[0], wt, bias, flip=fl | 4))
+            for order, f in (("2row", fl), ("1row", fl | 4), ("1r-lin", fl | 6)):
                 hot = timed(lambda: N.dwconv7x7_nhwc(xs[0], wt, bias, flip=f), 20)
 
                 def ring():

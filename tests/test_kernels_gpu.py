@@ -796,7 +796,8 @@ def test_convnext_block_fast_layout_path_matches_plain_path(N):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("shape", [(2, 96, 64, 64), (1, 768, 16, 16), (2, 192, 33, 21), (1, 4, 7, 70), (2, 384, 32, 32)])
+@pytest.mark.parametrize("shape", [(2, 96, 64, 64), (1, 768, 16, 16), (2, 192, 33, 21), (1, 4, 7, 70), (2, 384, 32, 32),
+                                   (1, 8, 1, 9), (1, 8, 2, 5), (1, 12, 5, 128)])
 def test_dwconv7x7_nhwc_forward_and_backward_data(N, shape):
     import torch.nn.functional as F
     g = torch.Generator().manual_seed(shape[1] + 1)
@@ -812,6 +813,20 @@ def test_dwconv7x7_nhwc_forward_and_backward_data(N, shape):
     y = N.dwconv7x7_nhwc(dev(x.permute(0, 2, 3, 1).contiguous()), dev(wt), dev(b))
     torch.testing.assert_close(y.cpu().permute(0, 3, 1, 2).double(), ref.detach(), rtol=1e-5, atol=1e-5)
     gx = N.dwconv7x7_nhwc(dev(gy.permute(0, 2, 3, 1).contiguous()), dev(wt), None, flip=True)
+    # the two-rows-per-lane kernel (default), the one-row kernel (flip bit 2) and the plain block order (bit 1) agree
+    # bit for bit: same accumulation order per output
+    xn = dev(x.permute(0, 2, 3, 1).contiguous())
+    gyn = dev(gy.permute(0, 2, 3, 1).contiguous())
+    skip = dev(torch.randn(gyn.shape, generator=g))
+    # fused skip-gradient add: bitwise the separate element-wise add, in both kernel variants
+    assert torch.equal(N.dwconv7x7_nhwc(gyn, dev(wt), None, flip=True, addend=skip), gx + skip)
+    assert torch.equal(N.dwconv7x7_nhwc(gyn, dev(wt), None, flip=5, addend=skip), gx + skip)
+    assert torch.equal(N.dwconv7x7_nhwc(xn, dev(wt), None, flip=0, addend=skip), N.dwconv7x7_nhwc(xn, dev(wt), None) + skip)
+    with pytest.raises(N.SeaNativeError):
+        N.dwconv7x7_nhwc(xn, dev(wt), dev(b), addend=skip)  # bias and addend are mutually exclusive
+    for bits in (2, 4, 6):
+        assert torch.equal(y, N.dwconv7x7_nhwc(xn, dev(wt), dev(b), flip=bits))
+        assert torch.equal(gx, N.dwconv7x7_nhwc(dev(gy.permute(0, 2, 3, 1).contiguous()), dev(wt), None, flip=1 | bits))
     torch.testing.assert_close(gx.cpu().permute(0, 3, 1, 2).double(), gx_ref, rtol=1e-5, atol=1e-5)
 
 

@@ -254,7 +254,10 @@ extern "C" int sea_dwconv7x7_nhwc_add(const float* x, const float* wt, const flo
   float4* y4 = (float4*)y;
   // flip bit 1 (value 2): plain linear block order; bit 2 (value 4): one output row per lane (A/B switches for
   // tools/dev/dwconv_bench.py)
-  const bool two_rows = !(flip & 4) && H >= 2;
+  // two rows per lane pay off on the large maps (96 ch 128^2: 42 vs 44 us forward, 37 vs 42 us backward-data; 192 ch
+  // 64^2: 21 vs 23 us) and lose on the small ones, where halving the number of blocks costs more than the loads saved
+  // (768 ch 16^2: 11.2 vs 8.7 us); profiles/r2_dwconv_rows_ab.log.  flip bit 3 (value 8) forces them.
+  const bool two_rows = !(flip & 4) && H >= 2 && ((flip & 8) || (int64_t)H * W >= 4096);
   const int HP = two_rows ? (H + 1) / 2 : H;
   const int64_t units64 = (int64_t)gx * HP * B;
   SEA_CHECK_ARG(units64 < (1ll << 30));

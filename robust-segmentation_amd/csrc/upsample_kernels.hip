@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void upsample_fwd_pow2_kernel(const float* __r
 // expression tree as upsample_fwd_kernel: identical values.
 template <int S>
 __device__ __forceinline__ void upsample_fwd_cell_item(const float* __restrict__ x, float* __restrict__ y, int h, int w,
-                                                       int x4, int c, int64_t plane) {
+                                                       int x4, int c, int64_t plane, bool nt) {
   constexpr int LOG = Pow2<S>::LOG;
   constexpr int G = (S / 2 >= 4) ? 4 : S / 2;
   constexpr float inv = 1.f / (float)S;
@@ -277,26 +277,31 @@ __device__ __forceinline__ void upsample_fwd_cell_item(const float* __restrict__
     o.y = (1.f - ly) * top[1] + ly * bot[1];
     o.z = (1.f - ly) * top[2] + ly * bot[2];
     o.w = (1.f - ly) * top[3] + ly * bot[3];
-    __builtin_nontemporal_store(o, reinterpret_cast<f4*>(yp + (int64_t)Y * W));
+    // non-temporal only for outputs that cannot stay in the 256 MB Infinity Cache anyway: a 176 MB logit tensor
+    // (C=21) is read back by the loss kernel right away and should still be on die then
+    if (nt)
+      __builtin_nontemporal_store(o, reinterpret_cast<f4*>(yp + (int64_t)Y * W));
+    else
+      *reinterpret_cast<f4*>(yp + (int64_t)Y * W) = o;
   }
 }
 
 template <int S>
 __global__ __launch_bounds__(256) void upsample_fwd_cells_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                  int h, int w, int64_t total, int xcd, FastDiv fW4,
-                                                                 FastDiv fC) {
+                                                                 FastDiv fC, int nt) {
   const int W4 = (w * S) >> 2, NC = h + 1;
   const IndexRange rg = xcd_range(total, xcd);
   if (total < kFastIndexLimit) {
     const uint32_t end = (uint32_t)rg.end, stride = (uint32_t)rg.stride;
     for (uint32_t i = (uint32_t)rg.begin; i < end; i += stride) {
       const uint32_t r = fdiv(i, fW4), plane = fdiv(r, fC);
-      upsample_fwd_cell_item<S>(x, y, h, w, (int)(i - r * W4), (int)(r - plane * NC) - 1, plane);
+      upsample_fwd_cell_item<S>(x, y, h, w, (int)(i - r * W4), (int)(r - plane * NC) - 1, plane, nt != 0);
     }
   } else {
     for (int64_t i = rg.begin; i < rg.end; i += rg.stride) {
       const int64_t r = i / W4;
-      upsample_fwd_cell_item<S>(x, y, h, w, (int)(i % W4), (int)(r % NC) - 1, r / NC);
+      upsample_fwd_cell_item<S>(x, y, h, w, (int)(i % W4), (int)(r % NC) - 1, r / NC, nt != 0);
     }
   }
 }
@@ -709,10 +714,15 @@ extern "C" int sea_upsample_bilinear_fwd(const float* x, float* y, int64_t plane
         const dim3 grid(grid_for_xcd(total, 256)), block(256);
         const int xo = xcd_order_enabled() == 2;
         const FastDiv fW4 = fast_div((uint32_t)(W / 4)), fC = fast_div((uint32_t)(h + 1));
+        static const int nt_mode = [] {  // SEA_UPSAMPLE_NT=0 / 1: never / always; default: by output size
+          const char* e = getenv("SEA_UPSAMPLE_NT");
+          return (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : 2;
+        }();
+        const int nt = nt_mode == 2 ? (planes * H * W * 4 > (192ll << 20)) : nt_mode;
         switch (S) {
-          case 4: hipLaunchKernelGGL(upsample_fwd_cells_kernel<4>, grid, block, 0, s, x, y, h, w, total, xo, fW4, fC); break;
-          case 8: hipLaunchKernelGGL(upsample_fwd_cells_kernel<8>, grid, block, 0, s, x, y, h, w, total, xo, fW4, fC); break;
-          default: hipLaunchKernelGGL(upsample_fwd_cells_kernel<16>, grid, block, 0, s, x, y, h, w, total, xo, fW4, fC); break;
+          case 4: hipLaunchKernelGGL(upsample_fwd_cells_kernel<4>, grid, block, 0, s, x, y, h, w, total, xo, fW4, fC, nt); break;
+          case 8: hipLaunchKernelGGL(upsample_fwd_cells_kernel<8>, grid, block, 0, s, x, y, h, w, total, xo, fW4, fC, nt); break;
+          default: hipLaunchKernelGGL(upsample_fwd_cells_kernel<16>, grid, block, 0, s, x, y, h, w, total, xo, fW4, fC, nt); break;
         }
         SEA_RETURN_LAST();
       }

@@ -118,6 +118,11 @@ def _stream() -> int:
     return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
+# A/B knob for in-loop measurements: SEA_K2_FORCE=<int> is passed as `force_vec` to every K2 launch that does not set
+# one itself (bits 4-7: tuning variant, see csrc/loss_kernels.hip)
+_K2_FORCE = int(os.environ.get("SEA_K2_FORCE", "0"), 0)
+
+
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -222,6 +227,8 @@ def loss_fwd_bwd(logits, y, weights, mode: int, track_mode: int, grad_scale: flo
     args = [_p(logits), DTYPE_CODE[logits.dtype], layout, _p(y), int_bytes(y), _p(weights), mode, track_mode, B, Cc,
             HW, grad_scale, _p(dlogits), _p(pred), 0 if pred is None else int_bytes(pred), _p(loss_px),
             _p(workspace), workspace.numel(), _p(out[0]), _p(out[1]), _p(out[2]), _stream()]
+    if not force_vec and _K2_FORCE:
+        force_vec = _K2_FORCE
     if force_vec:
         _check(L.sea_loss_fwd_bwd_tuned(*args, force_vec), "sea_loss_fwd_bwd_tuned")
     else:

@@ -46,7 +46,7 @@ def main():
             same = torch.equal(ya, yb)
             mb = 8 * xs[0].numel() / 1e6
             same = same and torch.equal(ya, N.dwconv7x7_nhwc(xs[0], wt, bias, flip=fl | 4))
-            for order, f in (("2row", fl), ("1row", fl | 4), ("1r-lin", fl | 6)):
+            for order, f in (("2row", fl | 8), ("1row", fl | 4), ("1r-lin", fl | 6)):
                 hot = timed(lambda: N.dwconv7x7_nhwc(xs[0], wt, bias, flip=f), 20)
 
                 def ring():

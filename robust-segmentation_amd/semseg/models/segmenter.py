@@ -2,8 +2,10 @@
 
 Own implementation for PyTorch-ROCm with the reference's state-dict schema (185
 tensors for ViT-S/16 with 151 classes; semseg/models/segmenter.py:196-353,
-backbones/vit_encoder.py:84-294, heads/segmenter_decoder.py:30-99).  Attention goes through
-``F.scaled_dot_product_attention`` (fused kernel on ROCm) instead of materialising softmax(QK^T).
+backbones/vit_encoder.py:84-294, heads/segmenter_decoder.py:30-99).  Attention goes through libsea_hip M7 (fp32 MFMA
+flash attention, deterministic backward) for fp32 HIP tensors with head dimension 64 and through
+``F.scaled_dot_product_attention`` otherwise, instead of materialising softmax(QK^T); LayerNorms with frozen parameters
+go through M5.
 Forward semantics: pad to a multiple of 16, encode, drop the class token, decode to (B,n_cls,H/16,W/16)
 masks, bilinear x16 back to the padded size, crop.
 """

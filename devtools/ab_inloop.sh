@@ -1,4 +1,4 @@
-python robust-segmentation_amd/tools/dev/dwconv_bench.py > gpurun_out/r2_dwconv_rows_ab.log 2>&1; cat gpurun_out/r2_dwconv_rows_ab.log | cut -c1-150
+python devtools/dwconv_bench.py > gpurun_out/r2_dwconv_rows_ab.log 2>&1; cat gpurun_out/r2_dwconv_rows_ab.log | cut -c1-150
 python -m pytest tests/test_kernels_gpu.py -m gpu -q -x -k "dwconv or block or upsample" 2>&1 | tail -3
 b() { python bench.py --steps 30 --warmup 5 --no-cpu-baseline "$@" 2>&1 | grep -o '"ms_per_step": [0-9.]*\|"avg_launch_ms": [0-9.]*' | tr '\n' ' '; echo; }
 echo "default:"; b

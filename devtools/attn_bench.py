@@ -4,7 +4,7 @@ attention) vs ATen scaled_dot_product_attention, forward and forward+backward, i
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "robust-segmentation_amd")]
 import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402

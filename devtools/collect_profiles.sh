@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the GPU box (raw output in /tmp, summaries into gpurun_out/ -> profiles/).
-#   gpurun -- 'bash robust-segmentation_amd/tools/dev/collect_profiles.sh r2'
+#   gpurun -- 'bash devtools/collect_profiles.sh r2'
 R=${1:-r2}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out
@@ -8,7 +8,7 @@ RAW=/tmp/sea_prof_$R
 mkdir -p $OUT $RAW
 export TMPDIR=/tmp
 cd $REPO
-CASES=robust-segmentation_amd/tools/dev/profile_cases.py
+CASES=devtools/profile_cases.py
 python3 $CASES > $OUT/${R}_cases.txt 2>$RAW/cases.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/cases -- python3 $CASES > $RAW/cases_kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $RAW/fetch -- python3 $CASES > $RAW/fetch.log 2>&1

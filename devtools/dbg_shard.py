@@ -1,6 +1,6 @@
 """Batch-composition probe: does image 0 get bitwise the same logits / input gradient whatever shares its batch?"""
 import os, sys, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "robust-segmentation_amd")]
 from semseg.models import UperNetForSemanticSegmentation
 from semseg import attacker as A

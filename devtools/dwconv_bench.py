@@ -2,7 +2,7 @@
 """M1 (depthwise 7x7, NHWC) A/B: two output rows per lane (default) vs one row, XCD-aware vs plain block order, on the four
 ConvNeXt-T stage shapes.
 
-    python robust-segmentation_amd/tools/dev/dwconv_bench.py
+    python devtools/dwconv_bench.py
 
 `hot` repeats one buffer pair (what the layer sees in the attack loop: its input was just written by the previous
 layer); `cold` walks a ring of buffers larger than the Infinity Cache.  Both orders must give identical bits.
@@ -10,7 +10,7 @@ layer); `cold` walks a ring of buffers larger than the Infinity Cache.  Both ord
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "robust-segmentation_amd")]
 
 import torch  # noqa: E402

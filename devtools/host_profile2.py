@@ -1,5 +1,5 @@
 import os, sys, time, gc
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "robust-segmentation_amd")]
 import torch
 import bench

@@ -3,7 +3,7 @@
 convolution modes of the UperNet head (Winograd F(4x4), F(2x2), MIOpen): is the final worst-case mIoU / aAcc the
 same to 0.05 percentage points?  Writes one JSON (-> profiles/r2_miou_claim.json).
 
-    python robust-segmentation_amd/tools/dev/miou_claim.py --n 16 --out gpurun_out/r2_miou_claim.json
+    python devtools/miou_claim.py --n 16 --out gpurun_out/r2_miou_claim.json
 """
 import argparse
 import json
@@ -12,7 +12,7 @@ import sys
 import tempfile
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "robust-segmentation_amd")
 sys.path[:0] = [ROOT, PKG]
 

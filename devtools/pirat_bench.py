@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """PIR-AT outer step as BASELINE configs[3] writes it: UperNet-ConvNeXt-S, ADE20K-shaped (C=151), 5-step CE PGD
-inner attack, batch 8 per GPU, fp32 vs bf16 autocast.   python robust-segmentation_amd/tools/dev/pirat_bench.py"""
+inner attack, batch 8 per GPU, fp32 vs bf16 autocast.   python devtools/pirat_bench.py"""
 import json
 import os
 import sys
 import tempfile
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "robust-segmentation_amd")
 sys.path[:0] = [ROOT, PKG]
 import yaml  # noqa: E402

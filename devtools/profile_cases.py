@@ -2,7 +2,7 @@
 """Launch every attack-side kernel a few times, COLD (ring of buffers > 1.5 GB where the working set is smaller than
 the 256 MiB Infinity Cache), for rocprofv3:
 
-    rocprofv3 --kernel-trace --stats -d gpurun_out/prof_cases -- python3 robust-segmentation_amd/tools/dev/profile_cases.py
+    rocprofv3 --kernel-trace --stats -d gpurun_out/prof_cases -- python3 devtools/profile_cases.py
     rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_fetch -- python3 .../profile_cases.py     (and WRITE_SIZE, SQ counters)
 
 Each case prints `CASE <tag> <kernel-name substring> <algorithmic bytes> <moved bytes>` so that
@@ -11,7 +11,7 @@ tools/summarize_profile.py --cases can price the kernel rows.  B=8, 512x512 thro
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "robust-segmentation_amd"), os.path.join(ROOT, "robust-segmentation_amd", "tools")]
 import torch  # noqa: E402
 

@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--write")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--title", default="B=8, C=21, 512x512, UperNet-ConvNeXt-T, fp32")
-    ap.add_argument("--cases", help="stdout of tools/dev/profile_cases.py (CASE lines) to price --kernels / --fetch / --write rows")
+    ap.add_argument("--cases", help="stdout of devtools/profile_cases.py (CASE lines) to price --kernels / --fetch / --write rows")
     ap.add_argument("--sq", help="rocprofv3 --pmc SQ_* output directory (per-kernel medians are tabulated)")
     a = ap.parse_args()
     out_dir = os.path.join(ROOT, "profiles")
@@ -158,7 +158,7 @@ def main():
         med = lambda v: sorted(v)[len(v) // 2]  # noqa: E731
         with open(os.path.join(out_dir, f"{a.round}_cold_kernel_roofline.md"), "w") as f:
             f.write(f"# Attack-side kernels, cold launches, rocprofv3 --kernel-trace ({a.round})\n\n"
-                    "`tools/dev/profile_cases.py`: B=8, 512x512, every launch on buffers that are not in the 256 MiB Infinity Cache "
+                    "`devtools/profile_cases.py`: B=8, 512x512, every launch on buffers that are not in the 256 MiB Infinity Cache "
                     "(ring of independent sets > 1.5 GB).  avg/min us = rocprofv3 kernel durations of the case's launches; "
                     "alg = SURVEY 8(d) bytes (int64 label + argmax), moved = bytes the kernel moves (uint8 label + argmax); "
                     "fractions of the 8 TB/s HBM3E peak.  PMC = 2 x FETCH_SIZE + WRITE_SIZE (separate passes; KiB; gfx950 "

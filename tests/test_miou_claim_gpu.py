@@ -17,7 +17,7 @@ statistic of a small sample carries that noise.  Measured on this set (profiles/
                       two runs of the MIOpen mode against each other: 0.25 / 0.20; device modes vs CPU: F(4x4) +0.21/+0.19,
                       F(2x2) +0.05/-0.05, MIOpen +0.42/+0.23 and +0.16/+0.03               -> test 2 asserts the control band
 
-and on the FULL-size run (16 x 512^2, 3 x 300 iterations; profiles/r2_miou_claim.json, tools/dev/miou_claim.py) the
+and on the FULL-size run (16 x 512^2, 3 x 300 iterations; profiles/r2_miou_claim.json, devtools/miou_claim.py) the
 three convolution modes agree to 0.006 points at eps 4/255, the two Winograd tiles to 0.0013 points at eps 8/255 and
 reproduce bit for bit run to run, while two MIOpen runs differ from each other by 0.14 (aAcc) / 0.07 (mIoU) points.
 So: no mode is distinguishable from the reference beyond the reference's own sensitivity to rounding-level

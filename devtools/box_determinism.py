@@ -26,6 +26,19 @@ import torch  # noqa: E402
 def main():
     from real_models import EPS, setup
     from semseg import val as V
+    if "--history" in sys.argv:
+        # a different allocation / library history before the measured model is built (what a pytest process that ran
+        # other models first looks like): UperNet-T 5-step SEA at B=2 and a Segmenter forward+backward
+        from semseg import attacker as A
+        g0, m0, x0, _, y0, w0, C0 = setup("upernet_t")
+        A.apgd_largereps(m0.cuda(), x0.cuda(), y0.cuda(), w0.cuda(), norm="Linf", eps=EPS, n_iter=5, use_rs=True,
+                         loss="mask-ce-avg", track_loss="ce-avg", num_classes=C0, early_stop=True)
+        g1, m1, x1_, _, y1, w1, C1 = setup("segmenter")
+        xin = x1_.cuda().requires_grad_(True)
+        m1.cuda()(xin).square().mean().backward()
+        del m0, m1, xin
+        keep = [torch.empty(n, device="cuda") for n in (12345, 777, 3 * 1000 * 1000 + 5)]   # shifts later addresses
+        print("history: ran UperNet-T SEA + Segmenter fwd/bwd first;", torch.cuda.memory_allocated() >> 20, "MiB held", flush=True)
     g, model, x, x1, y, w, C = setup("upernet_s")
     model, x, y = model.cuda(), x.cuda(), y.cuda()
     torch.manual_seed(int(g["pgd_seed"]))
@@ -41,6 +54,11 @@ def main():
         print(f"{tag:34s} x_adv sha1 {h}  logits sha1 {hl}  mismatching samples {n_bad}/4096", flush=True)
         return h
 
+    import platform
+    print("host:", platform.processor() or platform.machine(), "| cpu capability:", torch.backends.cpu.get_cpu_capability(),
+          "| GPU:", torch.cuda.get_device_properties(0).name, torch.cuda.get_device_properties(0).multi_processor_count, "CUs")
+    print("delta0 sha1", hashlib.sha1(delta0.cpu().numpy().tobytes()).hexdigest()[:12], "| weights sha1",
+          hashlib.sha1(b"".join(v.detach().cpu().numpy().tobytes() for v in model.state_dict().values())).hexdigest()[:12])
     db = os.path.expanduser("~/.config/miopen")
     print("user find-db before:", sorted(os.listdir(db)) if os.path.isdir(db) else None)
     torch.backends.cudnn.benchmark = False

@@ -34,6 +34,7 @@ def timed(fn, n):
 
 
 def main():
+    os.environ["SEA_DWCONV_AB_LIVE"] = "1"      # before the library reads it
     B = 8
     for Cc, hw in ((96, 128), (192, 64), (384, 32), (768, 16)):
         nset = max(2, int(1.6e9 // (8 * B * hw * hw * Cc)))
@@ -41,17 +42,19 @@ def main():
         wt = torch.randn(49, Cc, device="cuda") * 0.1
         bb = torch.randn(Cc, device="cuda")
         for name, bias, fl in (("fwd", bb, 0), ("bwd-data", None, 1)):
-            ya = N.dwconv7x7_nhwc(xs[0], wt, bias, flip=fl)
-            yb = N.dwconv7x7_nhwc(xs[0], wt, bias, flip=fl | 2)
-            same = torch.equal(ya, yb)
+            def run(x, ab):      # A/B switches travel through the environment (SEA_DWCONV_AB, read per call here)
+                os.environ["SEA_DWCONV_AB"] = str(ab)
+                return N.dwconv7x7_nhwc(x, wt, bias, flip=bool(fl))
+            ya = run(xs[0], 0)
+            same = torch.equal(ya, run(xs[0], 2))
             mb = 8 * xs[0].numel() / 1e6
-            same = same and torch.equal(ya, N.dwconv7x7_nhwc(xs[0], wt, bias, flip=fl | 4))
-            for order, f in (("2row", fl | 8), ("1row", fl | 4), ("1r-lin", fl | 6)):
-                hot = timed(lambda: N.dwconv7x7_nhwc(xs[0], wt, bias, flip=f), 20)
+            same = same and torch.equal(ya, run(xs[0], 4))
+            for order, f in (("2row", 8), ("1row", 4), ("1r-lin", 6)):
+                hot = timed(lambda: run(xs[0], f), 20)
 
                 def ring():
                     for x in xs:
-                        N.dwconv7x7_nhwc(x, wt, bias, flip=f)
+                        run(x, f)
                 cold = timed(ring, 1) / nset
                 print(f"M1 dwconv NHWC C={Cc:4d} {hw:3d}x{hw:<3d} {name:8s} {order:6s}  hot {hot * 1e3:7.1f} us {mb / hot / 1e3:6.2f} TB/s"
                       f"   cold {cold * 1e3:7.1f} us {mb / cold / 1e3:6.2f} TB/s   identical={same}", flush=True)

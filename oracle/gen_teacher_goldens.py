@@ -72,6 +72,11 @@ class Recorder(torch.nn.Module):
         return out
 
 
+def pgd_start(shape, eps, seed):
+    """U(-eps, eps) start of Pgd_Attack_1 (val.py:192-193), host-independent (restated in tests/teacher.py)"""
+    return eps * (2 * torch.rand(shape, generator=torch.Generator().manual_seed(seed)) - 1)
+
+
 def pack_gradient(g):
     """sign plane + zero list + 2-bit magnitude level of every element"""
     g = g.flatten()
@@ -199,10 +204,21 @@ def run_case(case):
         rec.evals = []
         rec.on_logits = lambda lg: dict(ce_mean=torch.nn.functional.cross_entropy(lg, y).detach().clone(),
                                         absmax=lg.abs().max())
-        torch.manual_seed(99)
-        xa, lg, _ = V.Pgd_Attack_1(epsilon=EPS, alpha=1e-2, num_iter=pgd_steps, los="pgd").adv_attack(rec, x, y)
-        torch.manual_seed(99)
-        delta = torch.zeros_like(x).uniform_(-EPS, EPS)
+        # the random start: Tensor.uniform_ on the CPU rounds differently per ATEN_CPU_CAPABILITY (from + u*(to-from) is
+        # contracted to an FMA in the AVX2/AVX512 builds, not in the default one), so the draw the reference asks for
+        # is served from torch.rand (exact 24-bit lattice) with separately rounded ops: identical on every host
+        real_uniform = torch.Tensor.uniform_
+
+        def served(self, a=0.0, b=1.0, **kw):
+            assert a == -b
+            return self.copy_(pgd_start(self.shape, b, 99))
+
+        torch.Tensor.uniform_ = served
+        try:
+            xa, lg, _ = V.Pgd_Attack_1(epsilon=EPS, alpha=1e-2, num_iter=pgd_steps, los="pgd").adv_attack(rec, x, y)
+        finally:
+            torch.Tensor.uniform_ = real_uniform
+        delta = pgd_start(x.shape, EPS, 99)
         out = dict(y=y.to(torch.uint8), eps=np.float64(EPS), alpha=np.float64(1e-2), seed=np.int64(99),
                    n_evals=np.int64(pgd_steps), sample_idx=sidx.to(torch.int32))
         for e, evl in enumerate(rec.evals):

@@ -237,6 +237,16 @@ __global__ __launch_bounds__(256, 2) void dwconv7x7_nhwc_2row_kernel(const float
 
 using namespace sea;
 
+// A/B switches of the NHWC depthwise launcher (development only; unset = shipped dispatch).  The variable is looked
+// up once per process unless SEA_DWCONV_AB_LIVE=1 asks for a lookup per call (the A/B bench flips it between launches).
+static inline int dwconv_ab_switches() {
+  static const int live = [] { const char* e = getenv("SEA_DWCONV_AB_LIVE"); return (e && e[0] == '1') ? 1 : 0; }();
+  static const int cached = [] { const char* e = getenv("SEA_DWCONV_AB"); return e ? atoi(e) : 0; }();
+  if (!live) return cached;
+  const char* e = getenv("SEA_DWCONV_AB");
+  return e ? atoi(e) : 0;
+}
+
 // x, y: (B,H,W,C) contiguous fp32, C % 4 == 0, C <= 1024; wt: (49, C) taps-major; bias (C) or NULL; addend (same
 // shape as y) or NULL: y = conv(x) + addend, added after the taps (bitwise what a separate element-wise add gives; the
 // backward of a residual block hands the skip gradient in here).
@@ -252,17 +262,19 @@ extern "C" int sea_dwconv7x7_nhwc_add(const float* x, const float* wt, const flo
   hipStream_t s = (hipStream_t)stream;
   const float4 *x4 = (const float4*)x, *w4 = (const float4*)wt, *b4 = (const float4*)bias, *a4 = (const float4*)addend;
   float4* y4 = (float4*)y;
-  // flip bit 1 (value 2): plain linear block order; bit 2 (value 4): one output row per lane (A/B switches for
-  // tools/dev/dwconv_bench.py)
-  // two rows per lane pay off on the large maps (96 ch 128^2: 42 vs 44 us forward, 37 vs 42 us backward-data; 192 ch
+  // `flip` is a boolean (any non-zero value = backward-data).  A/B switches for devtools/dwconv_bench.py come from the
+  // environment, read per call so that one process can compare variants: SEA_DWCONV_AB bit 1 (value 2): plain linear
+  // block order; bit 2 (value 4): one output row per lane; bit 3 (value 8): force two rows per lane.
+  // Two rows per lane pay off on the large maps (96 ch 128^2: 42 vs 44 us forward, 37 vs 42 us backward-data; 192 ch
   // 64^2: 21 vs 23 us) and lose on the small ones, where halving the number of blocks costs more than the loads saved
-  // (768 ch 16^2: 11.2 vs 8.7 us); profiles/r2_dwconv_rows_ab.log.  flip bit 3 (value 8) forces them.
-  const bool two_rows = !(flip & 4) && H >= 2 && ((flip & 8) || (int64_t)H * W >= 4096);
+  // (768 ch 16^2: 11.2 vs 8.7 us); profiles/r2_dwconv_rows_ab.log.
+  const int ab = dwconv_ab_switches();
+  const bool two_rows = !(ab & 4) && H >= 2 && ((ab & 8) || (int64_t)H * W >= 4096);
   const int HP = two_rows ? (H + 1) / 2 : H;
   const int64_t units64 = (int64_t)gx * HP * B;
   SEA_CHECK_ARG(units64 < (1ll << 30));
   const int units = (int)units64;
-  const int per_xcd = (flip & 2) ? 0 : (units + 7) / 8;
+  const int per_xcd = (ab & 2) ? 0 : (units + 7) / 8;
   dim3 grid(per_xcd ? per_xcd * 8 : units), block(256);
 #define SEA_DW_LAUNCH(F, BI, AD)                                                                                        \
   do {                                                                                                                  \
@@ -273,7 +285,7 @@ extern "C" int sea_dwconv7x7_nhwc_add(const float* x, const float* wt, const flo
       hipLaunchKernelGGL((dwconv7x7_nhwc_kernel<F, BI, AD>), grid, block, 0, s, x4, w4, b4, a4, y4, CG, H, W, spb, gx,   \
                          units, per_xcd);                                                                               \
   } while (0)
-  if (flip & 1) {
+  if (flip) {
     if (addend)
       SEA_DW_LAUNCH(true, false, true);
     else

@@ -274,8 +274,10 @@ extern "C" int sea_tap_gather_fwd(const float* G, float* extra, int accumulate, 
   const int64_t total = (int64_t)B * nBh * nBw * (C / 4);
   // the kernel indexes inside one image with 32-bit offsets
   SEA_CHECK_ARG((int64_t)H * W * (C / 4) < (1ll << 31) && (int64_t)h * w * 9 * (C / 4) < (1ll << 31));
-  const char* ge = getenv("SEA_UPSAMPLE_GENERAL");
-  const bool general_only = ge && ge[0] == '1';
+  static const int general_only = [] {   // looked up once: this launcher is on the attack's per-iteration path
+    const char* e = getenv("SEA_UPSAMPLE_GENERAL");
+    return (e && e[0] == '1') ? 1 : 0;
+  }();
 #define SEA_LAUNCH_TAP_FWD(SS)                                                                                          \
   hipLaunchKernelGGL(tap_gather_fwd_kernel<SS>, dim3(grid_for_xcd(total, 256)), dim3(256), 0, (hipStream_t)stream,      \
                      (const float4*)G, (float4*)extra, accumulate, C / 4, h, w, H, W, (float)h / (float)H,              \

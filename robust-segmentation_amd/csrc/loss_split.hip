@@ -110,7 +110,9 @@ __global__ __launch_bounds__(256, WAVES) void loss_nchw_split(const T* __restric
       }
     }
     int arg = cbase + argj;
-    if (__builtin_expect(s != s, 0)) {  // NaN / +-inf logits: the first NaN among the e's is torch.max's index
+    // NaN / +-inf logits: the first NaN among the e's is torch.max's index.  (Inactive tail lanes hold -inf everywhere,
+    // exp(-inf - -inf) = NaN: they must not drag the wave into the cold path.)
+    if (__builtin_expect(active && s != s, 0)) {
       int an = 0x7fffffff;
 #pragma unroll
       for (int j = CH - 1; j >= 0; --j) {

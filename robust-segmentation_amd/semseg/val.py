@@ -116,7 +116,8 @@ class Pgd_Attack:
         model.eval()
         X = X.detach().contiguous().float()
         B, HW = X.shape[0], X.shape[-2] * X.shape[-1]
-        y = _labels(y) if self.mode is not None else y
+        # val.py:152-155 hands `y.long()` to EVERY loss, 'l2-loss' included (float targets are truncated there)
+        y = _labels(y) if self.mode is not None else y.long()
         delta = torch.zeros_like(X)
         best_delta = torch.zeros_like(X)
         best = torch.zeros(B, device=X.device)

@@ -201,7 +201,7 @@ def _pin(t):
         return t
 
 
-def main(argv=None):
+def _main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--cfg", type=str, default="configs/pascalvoc_convnext.yaml")
     ap.add_argument("--eps", type=float, default=8.0)
@@ -291,7 +291,11 @@ def main(argv=None):
         make_attack_dirs(save_dir)
 
     def local_rows(idx):
-        return torch.tensor([pos[g_] for g_ in idx])
+        """a batch is a run of consecutive rows of this rank's shard: a SLICE, i.e. a view of the pinned host tensor
+        (a tensor index would gather into a pageable temporary and make the H2D copy synchronous)"""
+        j0 = pos[idx[0]]
+        assert pos[idx[-1]] == j0 + len(idx) - 1
+        return slice(j0, j0 + len(idx))
 
     def batch_to_device(idx):
         rows = local_rows(idx)
@@ -316,7 +320,7 @@ def main(argv=None):
         pred = predict(model, x, C)
         if labels is None:
             labels_h[rows] = pred.to(lbl_dtype).cpu()
-        y = labels_h[rows].to(device).long()
+        y = labels_h[rows].to(device, non_blocking=True).long()
         N.class_counts(pred, y.contiguous(), C, per_image=False, mask_pred=True, out=clean_tot)
     if not args.adversarial:
         return
@@ -330,7 +334,7 @@ def main(argv=None):
                             log_path=None, num_classes=C, early_stop=True)
         for idx in batches:
             x, rows = batch_to_device(idx)
-            y = labels_h[rows].to(device).long().contiguous()
+            y = labels_h[rows].to(device, non_blocking=True).long().contiguous()
             x_adv, _, acc, pred = attack_fn(model, x, y, weights, return_pred=True, noises=start_noise(idx, a))
             # predictions masked at ignored pixels, like the logs eval_performance hands to evalSEA (infer.py:88-90)
             im, pm, tc = N.class_counts(pred, y, C, per_image=True, mask_pred=True)
@@ -396,6 +400,16 @@ def main(argv=None):
     if rank == 0 and bool(args.cleanup):
         remove_dirs(save_dir)
     return summary
+
+
+def main(argv=None):
+    """`_main` with the process-global switch it sets (MIOpen find mode) restored on exit: a caller that runs this
+    in-process (tests do) must not inherit `cudnn.benchmark = True`."""
+    prev = torch.backends.cudnn.benchmark
+    try:
+        return _main(argv)
+    finally:
+        torch.backends.cudnn.benchmark = prev
 
 
 if __name__ == "__main__":

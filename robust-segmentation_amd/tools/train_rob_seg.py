@@ -84,7 +84,7 @@ def build_attack(train_cfg):
                                                        num_classes=int(train_cfg.get("N_CLS", 21)))[0]  # x_best, as the reference (train_rob_seg.py:336)
 
 
-def main(argv=None):
+def _main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--cfg", type=str, default="configs/ade20k_convnext.yaml")
     ap.add_argument("--world_size", type=int, default=None, help="accepted for CLI parity; torchrun's env wins")
@@ -220,6 +220,16 @@ def main(argv=None):
                        args.dump_params)
     if world > 1:
         dist.destroy_process_group()
+
+
+def main(argv=None):
+    """`_main` with the process-global switch it sets (MIOpen find mode) restored on exit: a caller that runs this
+    in-process (tests do) must not inherit `cudnn.benchmark = True`."""
+    prev = torch.backends.cudnn.benchmark
+    try:
+        return _main(argv)
+    finally:
+        torch.backends.cudnn.benchmark = prev
 
 
 if __name__ == "__main__":

@@ -47,3 +47,23 @@ def stage_noises(x, seed=4321):
     """the reference drew torch.rand_like(x) once per apgd_largereps stage from the CPU generator"""
     torch.manual_seed(seed)
     return [torch.rand_like(x) for _ in range(3)]
+
+
+class Bounds:
+    """Every tolerance of the end-to-end real-model checks goes through here: the MEASURED value is printed next to
+    its bound (pytest -s; profiles/r3_real_models_bounds.log holds two leases) and all violations are raised together
+    after the table, so a red run shows how far off every quantity was."""
+
+    def __init__(self, title):
+        self.title, self.rows = title, []
+
+    def check(self, name, value, bound):
+        self.rows.append((name, float(value), float(bound)))
+
+    def report(self):
+        print(f"\n[{self.title}]")
+        for name, v, b in self.rows:
+            print(f"  {name:58s} measured {v:11.4e}   bound {b:9.2e}   margin x{(b / v if v > 0 else float('inf')):.1f}"
+                  + ("   <-- VIOLATED" if v > b else ""))
+        bad = [(n, v, b) for n, v, b in self.rows if v > b]
+        assert not bad, bad

@@ -71,8 +71,8 @@ def replay_apgd(g, x):
 def replay_pgd(g, x):
     """(inputs X + delta_t the reference fed to the model, the deltas, the returned x_adv)"""
     eps, alpha = float(g["eps"]), float(g["alpha"])
-    torch.manual_seed(int(g["seed"]))
-    delta = torch.zeros_like(x).uniform_(-eps, eps)
+    # the generator served the reference's `delta.uniform_(-eps, eps)` from torch.rand (host-independent arithmetic)
+    delta = eps * (2 * torch.rand(x.shape, generator=torch.Generator().manual_seed(int(g["seed"]))) - 1)
     xs, deltas = [], []
     for e in range(int(g["n_evals"])):
         xs.append(x + delta)

@@ -324,6 +324,24 @@ int sea_attention_bwd(const float* q, const float* k, const float* v, int64_t sb
                       void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * M8  fp32 GEMM with frozen weights on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16) by operand splitting:
+ *     every fp32 operand is the exact sum of `terms` bf16 numbers (3: all 24 significant bits, six products, fp32-level
+ *     accuracy; 2: 16 bits, three products), fp32 accumulation, fixed order (bitwise reproducible).
+ *     replaces the hipBLASLt fp32 GEMMs behind the frozen-weight layers of the attacked model: the Winograd-domain
+ *     products of the UperNet head's 3x3 convolutions (semseg/models/uperforseg.py:200-215, 255-262), its 1x1
+ *     ConvModules (uperforseg.py:119-146) and the point-wise layers of the ConvNeXt blocks, forward and input gradient.
+ *   C[g] (M x N, row stride ldc) = A[g] (M x K fp32, row stride lda) * W[g]^T + bias[n], optional ReLU; g < batch,
+ *   batch strides in elements (A, C) / bytes (packed W).  K % 32 == 0, lda % 4 == 0, A 16-byte aligned.
+ * sea_gemm_split_pack: W (N x K row-major, or K x N with trans = 1; row stride ldw) -> the packed, pre-split image the
+ *   kernel reads ([K/32][terms][ceil128(N)][32] bf16, sea_gemm_split_packed_bytes bytes).  Done once per weight.
+ */
+int64_t sea_gemm_split_packed_bytes(int N, int K, int terms);
+int sea_gemm_split_pack(const float* W, int64_t ldw, int trans, int N, int K, int terms, void* out, void* stream);
+int sea_gemm_split(const float* A, int64_t lda, const void* Wp, float* C, int64_t ldc, const float* bias, int relu, int M,
+                   int N, int K, int terms, int batch, int64_t strideA, int64_t strideW_bytes, int64_t strideC,
+                   void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Measurement probes (bench.py / tools/kernel_bench.py only; nothing on the product path calls them).
  * sea_probe_stream_copy: dst[0:bytes] = src[0:bytes] with 16-byte-per-lane accesses (non_temporal != 0: nt loads and
  *   stores): the HBM copy ceiling the roofline fractions are also quoted against ("report against a

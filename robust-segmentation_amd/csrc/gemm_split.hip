@@ -1,0 +1,301 @@
+// M8 (model side): fp32 GEMM on the bf16 matrix cores by operand splitting.
+//
+//   C[g] (M x N, fp32) = A[g] (M x K, fp32, row-major) * W[g]^T (W: N x K, frozen weights) [+ bias[n]] [ReLU]
+//
+// The model side of an attack step is ~1.9 TFLOP of fp32 GEMMs with FROZEN weights (ConvNeXt point-wise layers, the
+// UperNet head's Winograd-domain products, reference semseg/models/uperforseg.py:200-215, 255-262 and
+// backbones/convnext.py blocks), which hipBLASLt runs on v_mfma_f32_32x32x2_f32 at 100-125 TFLOP/s (peak 157).  The
+// bf16 pipe is 16x faster per instruction.  An fp32 number is the exact sum of three bf16 numbers
+// (hi = bf16(a), mid = bf16(a - hi), lo = bf16(a - hi - mid): 3 x 8 significant bits = the 24 of fp32, and every
+// subtraction is exact), so
+//      a * w = hi*hi' + hi*mid' + mid*hi' + hi*lo' + mid*mid' + lo*hi'  (+ terms below 2^-24 relative: dropped)
+// is six v_mfma_f32_32x32x16_bf16 products accumulated in fp32: fp32-level accuracy at a 2.5 PFLOP/s / 6 = 416 TFLOP/s
+// ceiling.  TERMS = 2 keeps hi + mid (16 significant bits, 3 products, 833 TFLOP/s ceiling) for callers that accept it.
+//
+// Data flow per 128 x 128 output tile and 32-deep K step (256 threads, 4 waves as 2 x 2, 64 x 64 outputs per wave):
+//   A   : fp32 from global (any producer: no extra pass over the activations), split in registers (5.5 VALU ops per
+//         element, hidden in the MFMA shadow), written to LDS as TERMS bf16 images
+//   W   : split ONCE on the host side of the ABI (sea_gemm_split_pack) into the tile order the kernel reads:
+//         [K/32][TERMS][Npad][32] bf16, so a tile is TERMS contiguous 8 KB pieces
+//   LDS : [term][row][32 bf16] with the 16-byte chunk index XOR-swizzled by (row >> 2) & 3: both the 8/16-byte
+//         staging writes and the ds_read_b128 fragment reads of 32 consecutive rows are conflict-free, no padding
+//         (48 KB per block at TERMS = 3 -> three blocks per CU, which is what hides the staging phases)
+//   MFMA: per wave and 16-deep step 12 fragment reads feed 24 MFMAs (TERMS = 3): 0.5 LDS reads per MFMA
+//   The next tile's global loads are issued before the MFMAs of the current one (register prefetch).
+// Fixed summation order, no atomics: bitwise reproducible.  inf / NaN inputs: a +-inf operand gives NaN (inf - inf in
+// the split) where an fp32 GEMM may give inf.
+#include "sea_common.h"
+
+namespace sea {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int GS_BM = 128, GS_BN = 128, GS_BK = 32;
+constexpr int GS_IMG = GS_BM * GS_BK * 2;  // bytes of one term image (128 rows x 64 B)
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {  // low half = a
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+
+template <int TERMS>
+__device__ __forceinline__ void split4(const f32x4 v, u32x2 (&out)[TERMS]) {
+  float r0 = v[0], r1 = v[1], r2 = v[2], r3 = v[3];
+#pragma unroll
+  for (int t = 0; t < TERMS; ++t) {
+    const uint32_t p0 = pack_bf16(r0, r1), p1 = pack_bf16(r2, r3);
+    out[t] = u32x2{p0, p1};
+    if (t + 1 < TERMS) {  // exact: the rounded-off part of an fp32 number is itself an fp32 number
+      r0 -= __uint_as_float(p0 << 16);
+      r1 -= __uint_as_float(p0 & 0xffff0000u);
+      r2 -= __uint_as_float(p1 << 16);
+      r3 -= __uint_as_float(p1 & 0xffff0000u);
+    }
+  }
+}
+
+__device__ __forceinline__ int swz(int row, int chunk) { return (chunk ^ ((row >> 2) & 3)) << 4; }
+
+struct GemmSplitArgs {
+  const float* A;
+  const char* W;
+  float* C;
+  const float* bias;
+  int64_t lda, ldc, strideA, strideW, strideC;
+  int M, N, K, Npad;
+  int mblocks, nblocks, total, per_xcd;
+  int relu;
+};
+
+template <int TERMS>
+__global__ __launch_bounds__(256, 3) void gemm_split_kernel(const GemmSplitArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * TERMS * GS_IMG];
+  char* As = smem;
+  char* Bs = smem + TERMS * GS_IMG;
+
+  // ---- tile of this block: XCD k works on the k-th contiguous eighth of the tile list, n-blocks fastest, so the
+  // blocks that share an A tile run on one XCD at the same time and meet in its L2
+  const int M = p.M, N = p.N, K = p.K, Npad = p.Npad;   // (locals: the lambdas below must not take the address of p)
+  const int64_t lda = p.lda, ldc = p.ldc;
+  const int logical = (int)(blockIdx.x & 7) * p.per_xcd + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= p.per_xcd || logical >= p.total) return;
+  const int nb = logical % p.nblocks;
+  const int t2 = logical / p.nblocks;
+  const int mb = t2 % p.mblocks;
+  const int g = t2 / p.mblocks;
+  const int m0 = mb * GS_BM, n0 = nb * GS_BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+
+  // ---- staging assignment
+  // A: thread -> float4 column q of rows (tid >> 3) + 32 i
+  const int q = tid & 7, arow = tid >> 3;
+  const float* Ag = p.A + (int64_t)g * p.strideA + 4 * q;
+  float* const Cbase = p.C;
+  const float* const bias = p.bias;
+  const int64_t strideC = p.strideC;
+  const int relu = p.relu;
+  int64_t aoff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int row = m0 + arow + 32 * i;
+    row = row < M ? row : M - 1;  // tail rows: read something valid, never stored
+    aoff[i] = (int64_t)row * lda;
+  }
+  // W: 16-byte piece pc = tid + 256 i -> (term, row, chunk); a tile is TERMS contiguous 8 KB pieces of the packed array
+  const char* Wg = p.W + (int64_t)g * p.strideW + (int64_t)n0 * 64;
+  const int64_t w_term = (int64_t)Npad * 64, w_kb = (int64_t)TERMS * w_term;
+
+  f32x4 pa[4];
+  u32x4 pw[2 * TERMS];
+  auto fetch = [&](int kb) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pa[i] = *(const f32x4*)(Ag + aoff[i] + (int64_t)kb * GS_BK);
+#pragma unroll
+    for (int i = 0; i < 2 * TERMS; ++i) {
+      const int pc = tid + 256 * i;
+      pw[i] = *(const u32x4*)(Wg + (int64_t)kb * w_kb + (int64_t)(pc >> 9) * w_term + (pc & 511) * 16);
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u32x2 s[TERMS];
+      split4<TERMS>(pa[i], s);
+      const int row = arow + 32 * i;
+#pragma unroll
+      for (int t = 0; t < TERMS; ++t) *(u32x2*)(As + t * GS_IMG + row * 64 + swz(row, q >> 1) + (q & 1) * 8) = s[t];
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * TERMS; ++i) {
+      const int pc = tid + 256 * i, term = pc >> 9, row = (pc & 511) >> 2, chunk = pc & 3;
+      *(u32x4*)(Bs + term * GS_IMG + row * 64 + swz(row, chunk)) = pw[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  const int nkb = K / GS_BK;
+  fetch(0);
+  for (int kb = 0; kb < nkb; ++kb) {
+    stage();
+    __syncthreads();
+    fetch(kb + 1 < nkb ? kb + 1 : kb);  // (unconditional: the last step re-reads its own tile, nothing is staged from it)
+    __builtin_amdgcn_sched_barrier(0);   // the loads go out BEFORE the MFMAs (the scheduler sinks them to the loop end otherwise)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 a[2][TERMS], b[2][TERMS];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int row = wm * 64 + mi * 32 + r;
+#pragma unroll
+        for (int t = 0; t < TERMS; ++t) a[mi][t] = *(const bf16x8*)(As + t * GS_IMG + row * 64 + swz(row, 2 * s + h));
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int row = wn * 64 + ni * 32 + r;
+#pragma unroll
+        for (int t = 0; t < TERMS; ++t) b[ni][t] = *(const bf16x8*)(Bs + t * GS_IMG + row * 64 + swz(row, 2 * s + h));
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          f32x16 c = acc[mi][ni];
+          // smallest products first
+          if constexpr (TERMS == 3) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][2], b[ni][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][1], c, 0, 0, 0);
+          }
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][0], c, 0, 0, 0);
+          acc[mi][ni] = c;
+        }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane = column, 16 registers = rows (reg & 3) + 8 (reg >> 2) + 4 h of the 32 x 32 tile
+  float* Cg = Cbase + (int64_t)g * strideC;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int col = n0 + wn * 64 + ni * 32 + r;
+    if (col >= N) continue;
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int rbase = m0 + wm * 64 + mi * 32 + 4 * h;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = rbase + (e & 3) + 8 * (e >> 2);
+        if (row < M) {
+          float v = acc[mi][ni][e] + bv;
+          if (relu) v = v > 0.f ? v : 0.f;
+          Cg[(int64_t)row * ldc + col] = v;
+        }
+      }
+    }
+  }
+}
+
+// W (fp32) -> [K/32][TERMS][Npad][32] bf16.  trans = 0: W is (N, K) row-major with row stride ldw; trans = 1: W is
+// (K, N) row-major (out[n][k] = W[k][n]).  Rows n >= N are zero.
+template <int TERMS>
+__global__ void gemm_split_pack_kernel(const float* __restrict__ W, int64_t ldw, int trans, int N, int K, int Npad,
+                                       uint16_t* __restrict__ out) {
+  const int64_t total = (int64_t)(K / 32) * Npad * 32;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int kk = (int)(i & 31);
+    const int64_t t = i >> 5;
+    const int n = (int)(t % Npad);
+    const int kb = (int)(t / Npad);
+    const int k = kb * 32 + kk;
+    float rem = 0.f;
+    if (n < N) rem = trans ? W[(int64_t)k * ldw + n] : W[(int64_t)n * ldw + k];
+#pragma unroll
+    for (int term = 0; term < TERMS; ++term) {
+      const uint32_t pk = pack_bf16(rem, 0.f);
+      out[(((int64_t)kb * TERMS + term) * Npad + n) * 32 + kk] = (uint16_t)(pk & 0xffffu);
+      rem -= __uint_as_float(pk << 16);
+    }
+  }
+}
+
+}  // namespace sea
+
+using namespace sea;
+
+static inline int gs_npad(int N) { return (N + GS_BN - 1) / GS_BN * GS_BN; }
+
+extern "C" int64_t sea_gemm_split_packed_bytes(int N, int K, int terms) {
+  if (N <= 0 || K <= 0 || K % GS_BK || (terms != 2 && terms != 3)) return -1;
+  return (int64_t)(K / GS_BK) * terms * gs_npad(N) * GS_BK * 2;
+}
+
+extern "C" int sea_gemm_split_pack(const float* W, int64_t ldw, int trans, int N, int K, int terms, void* out,
+                                   void* stream) {
+  SEA_CHECK_ARG(W && out && N > 0 && K > 0 && (K % GS_BK) == 0 && (terms == 2 || terms == 3));
+  SEA_CHECK_ARG(ldw >= (trans ? N : K));
+  const int Npad = gs_npad(N);
+  const int64_t total = (int64_t)(K / 32) * Npad * 32;
+  const int grid = grid_for(total, 256);
+  if (terms == 3)
+    hipLaunchKernelGGL(gemm_split_pack_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, ldw, trans, N, K, Npad,
+                       (uint16_t*)out);
+  else
+    hipLaunchKernelGGL(gemm_split_pack_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, ldw, trans, N, K, Npad,
+                       (uint16_t*)out);
+  SEA_RETURN_LAST();
+}
+
+extern "C" int sea_gemm_split(const float* A, int64_t lda, const void* Wp, float* C, int64_t ldc, const float* bias,
+                              int relu, int M, int N, int K, int terms, int batch, int64_t strideA, int64_t strideW_bytes,
+                              int64_t strideC, void* stream) {
+  SEA_CHECK_ARG(A && Wp && C && M > 0 && N > 0 && K > 0 && (K % GS_BK) == 0 && batch > 0 && (terms == 2 || terms == 3));
+  SEA_CHECK_ARG(lda >= K && ldc >= N && (lda % 4) == 0);
+  SEA_CHECK_ARG(((((uintptr_t)A) | ((uintptr_t)Wp)) & 15) == 0 && (((uintptr_t)C) & 3) == 0 && (strideA % 4) == 0 &&
+                (strideW_bytes % 16) == 0);
+  GemmSplitArgs p;
+  p.A = A;
+  p.W = (const char*)Wp;
+  p.C = C;
+  p.bias = bias;
+  p.lda = lda;
+  p.ldc = ldc;
+  p.strideA = strideA;
+  p.strideW = strideW_bytes;
+  p.strideC = strideC;
+  p.M = M;
+  p.N = N;
+  p.K = K;
+  p.Npad = gs_npad(N);
+  p.mblocks = (M + GS_BM - 1) / GS_BM;
+  p.nblocks = p.Npad / GS_BN;
+  const int64_t total = (int64_t)p.mblocks * p.nblocks * batch;
+  SEA_CHECK_ARG(total < (1ll << 30));
+  p.total = (int)total;
+  p.per_xcd = (p.total + 7) / 8;
+  p.relu = relu;
+  const dim3 grid(p.per_xcd * 8), block(256);
+  if (terms == 3)
+    hipLaunchKernelGGL(gemm_split_kernel<3>, grid, block, 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(gemm_split_kernel<2>, grid, block, 0, (hipStream_t)stream, p);
+  SEA_RETURN_LAST();
+}

@@ -67,6 +67,9 @@ _SIGS = {
     "sea_attention_fwd": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "sea_attention_bwd": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                _i64, _i64, _i64, _vp]),
+    "sea_gemm_split_packed_bytes": (_i64, [_i, _i, _i]),
+    "sea_gemm_split_pack": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp]),
+    "sea_gemm_split": (_i, [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _vp]),
     "sea_probe_stream_copy": (_i, [_vp, _vp, _sz, _i, _vp]),
     "sea_probe_stream_read": (_i, [_vp, _vp, _sz, _vp]),
 }
@@ -488,7 +491,7 @@ def wino_filter(weight, m: int, flip: bool):
 
 
 def wino_conv3x3_cl(x, U, m: int, bias=None, scale=None, relu: bool = False, gate=None, gate_scale=None,
-                    addend=None):
+                    addend=None, gemm_terms: int = 0):
     """3x3 / stride 1 / pad 1 convolution of a channels_last (B,Cin,H,W) tensor (or channel slice) -- or of the
     channel concatenation of a list of such tensors, which is never materialised -- with Winograd-domain filters
     U (A*A, Cin, Cout); returns channels_last (B,Cout,H,W) = act(scale[c] * (conv + addend) + bias[c]).
@@ -516,8 +519,16 @@ def wino_conv3x3_cl(x, U, m: int, bias=None, scale=None, relu: bool = False, gat
         _check(L.sea_wino_input_transform(_p(t), xps, _p(gate), _p(gate_scale), V.data_ptr() + 4 * off, Cin, B, t.shape[1],
                                           H, W, m, _stream()), "sea_wino_input_transform")
         off += t.shape[1]
-    with torch.autocast("cuda", enabled=False):
-        Mx = _f32c(torch.bmm(V, U))  # (A*A) independent fp32 GEMMs: hipBLASLt strided-batched
+    if gemm_terms in (2, 3) and Cin % 32 == 0 and T >= 256:
+        # M8: the (A*A) Winograd-domain products on the bf16 matrix cores (operands split into bf16 terms, fp32 accumulate)
+        Up = getattr(U, "_sea_packed", None)
+        if Up is None or Up.terms != gemm_terms:
+            Up = gemm_split_pack(U, trans=True, terms=gemm_terms)
+            U._sea_packed = Up                      # U is the cached, frozen filter image: packed once
+        Mx = gemm_split(V, Up)
+    else:
+        with torch.autocast("cuda", enabled=False):
+            Mx = _f32c(torch.bmm(V, U))  # (A*A) independent fp32 GEMMs: hipBLASLt strided-batched
     del V
     y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=xs[0].device, memory_format=torch.channels_last)
     if addend is not None and (tuple(addend.shape) != (B, Cout, H, W) or cl_pixel_stride(addend) != Cout):
@@ -628,3 +639,55 @@ def worst_miou_greedy(ints: torch.Tensor, unions: torch.Tensor, mt_state, n_roun
                                      C.addressof(miou), sel.ctypes.data, C.addressof(rounds))
     _check(rc, "sea_worst_miou_greedy")
     return miou.value, sel.tolist(), rounds.value, tuple(int(v) for v in mt)
+
+
+# ------------------------------------------------------------------------------------------------ M8
+class PackedWeight:
+    """Frozen weights W (N x K) pre-split into `terms` bf16 images in the tile order of sea_gemm_split
+    (optionally a batch of them, e.g. the (m+2)^2 Winograd-domain filters)."""
+
+    def __init__(self, data, N, K, terms, batch):
+        self.data, self.N, self.K, self.terms, self.batch = data, N, K, terms, batch
+        self.stride = data.numel() // batch
+
+
+def gemm_split_pack(W, trans: bool = False, terms: int = 3) -> PackedWeight:
+    """W: (N, K) fp32 (or (K, N) with ``trans``), or a batch (G, N, K) / (G, K, N) of them; last dim contiguous."""
+    _dev(W)
+    if W.dtype != torch.float32 or W.dim() not in (2, 3) or W.stride(-1) != 1:
+        raise SeaNativeError("gemm_split_pack: float32 (N,K) / (G,N,K) weights with a contiguous last dim expected")
+    Wb = W if W.dim() == 3 else W.unsqueeze(0)
+    G = Wb.shape[0]
+    N, K = (Wb.shape[2], Wb.shape[1]) if trans else (Wb.shape[1], Wb.shape[2])
+    L = lib()
+    nbytes = L.sea_gemm_split_packed_bytes(N, K, terms)
+    if nbytes < 0:
+        raise SeaNativeError(f"gemm_split_pack: unsupported shape N={N} K={K} terms={terms} (K % 32 == 0, terms 2 or 3)")
+    out = torch.empty(G, nbytes, dtype=torch.uint8, device=W.device)
+    for g in range(G):
+        _check(L.sea_gemm_split_pack(_p(Wb[g]), Wb.stride(1), int(trans), N, K, terms, _p(out[g]), _stream()),
+               "sea_gemm_split_pack")
+    return PackedWeight(out, N, K, terms, G)
+
+
+def gemm_split(A, Wp: PackedWeight, bias=None, relu: bool = False, out=None):
+    """out (.., N) = A (.., K) @ W^T [+ bias] [ReLU] with W pre-split (``gemm_split_pack``).  A: fp32, last dim
+    contiguous; 2-D (M, K) with any 4-aligned row stride, or (G, M, K) against a batch of G packed weights."""
+    _dev(A, bias, out)
+    batched = Wp.batch > 1 or A.dim() == 3
+    A3 = A if A.dim() == 3 else A.unsqueeze(0)
+    if (A.dtype != torch.float32 or A3.dim() != 3 or A3.shape[0] != Wp.batch or A3.shape[2] != Wp.K
+            or A3.stride(2) != 1):
+        raise SeaNativeError("gemm_split: A must be float32 (M,K) / (G,M,K) with K matching the packed weights")
+    G, M, K = A3.shape
+    if out is None:
+        out = torch.empty((G, M, Wp.N) if batched else (M, Wp.N), dtype=torch.float32, device=A.device)
+    O3 = out if out.dim() == 3 else out.unsqueeze(0)
+    if O3.shape != (G, M, Wp.N) or O3.stride(2) != 1 or out.dtype != torch.float32:
+        raise SeaNativeError("gemm_split: output must be float32 (.., M, N) with a contiguous last dim")
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != Wp.N or not bias.is_contiguous()):
+        raise SeaNativeError("gemm_split: bias must be contiguous float32 of N entries")
+    _check(lib().sea_gemm_split(_p(A3), A3.stride(1), _p(Wp.data), _p(O3), O3.stride(1), _p(bias), int(relu), M, Wp.N, K,
+                                Wp.terms, G, A3.stride(0) if G > 1 else 0, Wp.stride, O3.stride(0) if G > 1 else 0,
+                                _stream()), "sea_gemm_split")
+    return out

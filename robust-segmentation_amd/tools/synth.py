@@ -68,10 +68,12 @@ def image_noises(idx, a: int, shape, device, seed: int = 225):
 
 
 def sea_evaluate(model, images, labels, weights, eps: float, n_iter: int, batch: int = 8,
-                 losses=("mask-ce-bal", "mask-ce-avg", "js-avg")):
+                 losses=("mask-ce-bal", "mask-ce-avg", "js-avg"), noise_fn=None, tables=None):
     """Full SEA evaluation of host tensors ``images`` (N,3,H,W), ``labels`` (N,H,W) on the model's device.  Returns
     ``(preds (A,N,H,W) int64 on the host, worst-case aAcc, worst-case mIoU)`` with the reference's arithmetic
-    (tools/worse_only.py:279-334, 351-422)."""
+    (tools/worse_only.py:279-334, 351-422).  ``noise_fn(idx, a)`` supplies the three random-start draws of a batch
+    (default: the per-image device streams of tools/infer.py); a dict passed as ``tables`` receives the per-attack
+    per-image ``inter`` / ``union`` (A,N,C) and ``valid`` (N) counts the worst-case numbers were computed from."""
     from semseg import _native as N
     from semseg import attacker
     from tools.worse_only import worst_acc_from_counts, worst_miou_from_tables
@@ -87,12 +89,16 @@ def sea_evaluate(model, images, labels, weights, eps: float, n_iter: int, batch:
             x, y = images[idx].to(dev), labels[idx].to(dev).contiguous()
             _, _, _, p = attacker.apgd_largereps(model, x, y, weights.to(dev), norm="Linf", eps=eps, n_iter=n_iter, use_rs=True,
                                                  loss=loss, track_loss="ce-avg", early_stop=True, num_classes=C,
-                                                 return_pred=True, noises=image_noises(idx, a, tuple(x.shape[1:]), dev))
+                                                 return_pred=True,
+                                                 noises=(noise_fn(idx, a) if noise_fn is not None
+                                                         else image_noises(idx, a, tuple(x.shape[1:]), dev)))
             im, pm, tc = N.class_counts(p, y, C, per_image=True, mask_pred=True)
             inter[a, idx], union[a, idx], valid[idx] = im.cpu(), (tc + pm - im).cpu(), tc.sum(-1).cpu()
             pl = p.long()
             pl[y == -1] = -1
             preds[a, idx] = pl.cpu()
+    if tables is not None:
+        tables.update(inter=inter, union=union, valid=valid)
     worst, _, _ = worst_acc_from_counts(inter.sum(-1), valid)
     st = random.getstate()
     random.seed(225)

@@ -1,129 +1,95 @@
-"""The north_star's second metric: |mIoU_build - mIoU_reference| and |aAcc_build - aAcc_reference| <= 0.05 percentage
-points on a FULL SEA evaluation (3 losses, worst case over the attacks: reference tools/worse_only.py:279-334, 351-422).
-`-m gpu`; the CPU side is the oracle's restatement of the reference loop.
+"""The north_star's second metric, against the REFERENCE ITSELF: |mIoU_build - mIoU_reference| and
+|aAcc_build - aAcc_reference| of a full SEA evaluation (3 losses x 100 iterations, worst case over the attacks:
+reference tools/infer.py:332-408, tools/worse_only.py:279-334, 351-422).  `-m gpu`.
 
-Set-up (tools/synth.py): 16 images of 128x128, random-init UperNet-ConvNeXt-T whose classifier bias is fitted so that
-the clean prediction populates all 21 classes evenly -> every per-class IoU rests on thousands of pixels (round 1
-measured a 2.7-point spread between convolution modes on an ILL-conditioned set: ~10 populated classes, single
-pixels moving 1/(n+1) of the mean).  Reduced in size so that the CPU runs take minutes.
+Reference side: tests/golden/miou_ref/ holds the per-attack per-image intersection / union tables that the REAL
+reference produced on CPU (oracle/gen_miou_reference.py: unmodified apgd_largereps + evalSEA) on parts of 64 synthetic
+128x128 images; nothing of the reference or of the CPU oracle runs on the GPU box.  Device side: the product path
+(tools/synth.sea_evaluate = the loop of tools/infer.py) on the same model, images, labels, batches and random starts.
 
-What can and cannot be asserted.  The attack is chaotic: sign steps amplify last-bit differences of the convolutions
-into different adversarial images, so implementations agree statistically, not pixel-wise, and the worst-case
-statistic of a small sample carries that noise.  Measured on this set (profiles/r2_miou_horizon_probe.log):
-
-  3 x 15 iterations:  every device mode within 0.04 points of the CPU path (F(4x4) -0.037/-0.038, F(2x2) +0.009/+0.002,
-                      MIOpen +0.028/+0.012 and +0.006/+0.001 on a second run)                         -> test 1 asserts 0.08
-  3 x 60 iterations:  the CPU path against ITSELF with 1e-6 uniform noise added to the images: 0.148 / 0.013 points;
-                      two runs of the MIOpen mode against each other: 0.25 / 0.20; device modes vs CPU: F(4x4) +0.21/+0.19,
-                      F(2x2) +0.05/-0.05, MIOpen +0.42/+0.23 and +0.16/+0.03               -> test 2 asserts the control band
-
-and on the FULL-size run (16 x 512^2, 3 x 300 iterations; profiles/r2_miou_claim.json, devtools/miou_claim.py) the
-three convolution modes agree to 0.006 points at eps 4/255, the two Winograd tiles to 0.0013 points at eps 8/255 and
-reproduce bit for bit run to run, while two MIOpen runs differ from each other by 0.14 (aAcc) / 0.07 (mIoU) points.
-So: no mode is distinguishable from the reference beyond the reference's own sensitivity to rounding-level
-perturbations; the 0.05-point bar is met where the horizon is short enough for it to be measurable on 16 images."""
-import os
+The attack is a chaotic iteration: two correct implementations (and the reference against itself with a different
+thread count) end in different adversarial images, so the worst-case statistics agree statistically, not image by
+image.  The test therefore reports, per radius, the PAIRED per-image difference of the worst-case accuracy with its
+95 % confidence interval, and the difference of the worst-case mIoU with a paired bootstrap interval over images, and
+asserts that the difference is (a) within the north_star's 0.05 points or (b) inside its own 95 % interval, i.e. not
+distinguishable from zero at the committed sample size.  Measured values: profiles/r3_miou_vs_reference.log.
+"""
 import random
 
+import numpy as np
 import pytest
 import torch
 
-from conftest import PKG
-from oracle import sea_oracle as O
+import miou_ref as R
 
 pytestmark = pytest.mark.gpu
 
-N_IMG, SIZE, N_ITER, EPS, C = 16, 128, 60, 8.0 / 255, 21
-LOSSES = ("mask-ce-bal", "mask-ce-avg", "js-avg")
 
-
-def _case():
+@pytest.fixture(scope="module")
+def model():
     from semseg.models import UperNetForSemanticSegmentation
-    from semseg.utils.utils import VOC_WTS
-    from tools.synth import balance_classes
     torch.manual_seed(0)
-    model = UperNetForSemanticSegmentation("ConvNeXt-T_CVST", C, None).eval().cuda()
-    images = torch.rand(N_IMG, 3, SIZE, SIZE, generator=torch.Generator().manual_seed(1234))
-    frac = balance_classes(model, images)
-    assert float(frac.min()) >= 0.02, frac                       # every class holds >= 2 % of the pixels
+    m = UperNetForSemanticSegmentation("ConvNeXt-T_CVST", R.C, None).eval().cuda()
     with torch.no_grad():
-        labels = model(images.cuda()).max(1)[1].cpu()
-    return model, images, labels, torch.tensor(VOC_WTS)
+        m.decode_head.classifier.bias.copy_(R.bias().cuda())
+    return m
 
 
-def _worst_case(preds, labels):
-    """(worst-case aAcc, worst-case mIoU) in PERCENT from the per-attack argmax maps, reference arithmetic"""
-    ints, unions = O.per_image_tables(preds, labels, C)
-    worst_acc, _, _ = O.worst_case_acc(preds, labels, C)
-    miou, _, _ = O.worst_case_miou(ints, unions, rng=random.Random(225))
-    return 100.0 * worst_acc, 100.0 * miou
-
-
-def _gpu_run(model, images, labels, w, tile):
-    from semseg.models import convnext_upernet as M
+def _device_tables(model, eps255):
+    from semseg.utils.utils import VOC_WTS
     from tools.synth import sea_evaluate
-    old, M.WINOGRAD_TILE = M.WINOGRAD_TILE, tile
-    try:
-        preds, acc, miou = sea_evaluate(model, images, labels, w, EPS, N_ITER, batch=4, losses=LOSSES)
-    finally:
-        M.WINOGRAD_TILE = old
-    # the device-side tables + host C++ greedy give the oracle's numbers for the same maps
-    acc_o, miou_o = _worst_case(preds, labels)
-    assert 100.0 * acc == pytest.approx(acc_o, rel=1e-6) and 100.0 * miou == pytest.approx(miou_o, rel=1e-9)
-    return preds
+    w = torch.tensor(VOC_WTS)
+    ref_i, ref_u, dev_i, dev_u = [], [], [], []
+    for part, d in R.parts(eps255):
+        images = R.part_images(part)
+        labels = torch.from_numpy(d["labels"]).long()
+        with torch.no_grad():                                   # the labels ARE the model's clean prediction
+            clean = torch.cat([model(images[i:i + 16].cuda()).max(1)[1].cpu() for i in range(0, R.PART, 16)])
+        assert (clean != labels).float().mean().item() <= 1e-3, (clean != labels).float().mean().item()
+
+        def noise_fn(idx, a, part=part):
+            return [torch.stack([R.start_noise(part * R.PART + j, a, st) for j in idx]).cuda() for st in range(3)]
+
+        t = {}
+        sea_evaluate(model, images, labels, w, eps255 / 255.0, int(d["n_iter"]), batch=16, losses=R.LOSSES,
+                     noise_fn=noise_fn, tables=t)
+        ref_i.append(torch.from_numpy(d["ints"]).long())
+        ref_u.append(torch.from_numpy(d["unions"]).long())
+        dev_i.append(t["inter"])
+        dev_u.append(t["union"])
+    cat = lambda xs: torch.cat(xs, 1)
+    return cat(ref_i), cat(ref_u), cat(dev_i), cat(dev_u)
 
 
-def _cpu_run(model, images, labels, w):
-    from tools.synth import image_noises
-    cpu = model.cpu()
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))
-    preds = []
-    try:
-        for a, loss in enumerate(LOSSES):
-            out = []
-            for i in range(0, N_IMG, 4):
-                idx = list(range(i, i + 4))
-                noises = [t.cpu() for t in image_noises(idx, a, (3, SIZE, SIZE), "cuda")]   # the streams the device path draws
-                xa, _, _ = O.apgd_largereps(cpu, images[idx], labels[idx], w, eps=EPS, n_iter=N_ITER, use_rs=True,
-                                            loss=loss, track_loss="ce-avg", early_stop=True, noises=noises)
-                with torch.no_grad():
-                    out.append(cpu(xa).max(1)[1])
-            preds.append(torch.cat(out))
-    finally:
-        model.cuda()
-    return torch.stack(preds)
-
-
-def _rows(model, images, labels, w, n_iter, extra_cpu=None):
-    global N_ITER
-    N_ITER = n_iter
-    ref = _worst_case(_cpu_run(model, images, labels, w), labels)
-    rows = {"cpu oracle": ref}
-    if extra_cpu is not None:
-        rows["cpu oracle, images + 1e-6 noise"] = _worst_case(_cpu_run(model, extra_cpu, labels, w), labels)
-    for tile, name in ((4, "F(4x4) default"), (2, "F(2x2)"), (0, "MIOpen")):
-        rows[name] = _worst_case(_gpu_run(model, images, labels, w, tile), labels)
-    for name, (acc, miou) in rows.items():
-        print(f"3 x {n_iter:3d} iterations  {name:32s} worst-case aAcc {acc:8.4f} %   worst-case mIoU {miou:8.4f} %   "
-              f"delta vs cpu: {acc - ref[0]:+.4f} / {miou - ref[1]:+.4f} points")
-    assert 1.0 < ref[1] < 60.0                                    # the attack bites and the metric is not degenerate
-    return rows, ref
-
-
-def test_short_horizon_sea_matches_the_cpu_reference_path():
-    """3 x 15 iterations: trajectories have not decorrelated yet -> the claim's bar is measurable on 16 images."""
-    model, images, labels, w = _case()
-    rows, (ref_acc, ref_miou) = _rows(model, images, labels, w, 15)
-    for name, (acc, miou) in rows.items():
-        assert abs(acc - ref_acc) <= 0.08 and abs(miou - ref_miou) <= 0.08, (name, acc - ref_acc, miou - ref_miou)
-
-
-def test_long_horizon_sea_stays_inside_the_reference_paths_own_noise_band():
-    """3 x 60 iterations: device modes vs the CPU path, against the CPU path's own response to 1e-6 image noise."""
-    model, images, labels, w = _case()
-    pert = (images + (torch.rand(images.shape, generator=torch.Generator().manual_seed(9)) - 0.5) * 2e-6).clamp(0.0, 1.0)
-    rows, (ref_acc, ref_miou) = _rows(model, images, labels, w, 60, extra_cpu=pert)
-    ctrl = rows.pop("cpu oracle, images + 1e-6 noise")
-    band = max(0.6, 4.0 * max(abs(ctrl[0] - ref_acc), abs(ctrl[1] - ref_miou)))
-    for name, (acc, miou) in rows.items():
-        assert abs(acc - ref_acc) <= band and abs(miou - ref_miou) <= band, (name, acc - ref_acc, miou - ref_miou, band)
+@pytest.mark.parametrize("eps255", [8, 4])
+def test_worst_case_metrics_match_the_reference(model, eps255):
+    if not R.parts(eps255):
+        pytest.skip(f"no reference part committed for eps {eps255}/255")
+    ref_i, ref_u, dev_i, dev_u = _device_tables(model, eps255)
+    n = ref_i.shape[1]
+    valid = torch.full((n,), R.SIZE * R.SIZE)
+    acc_r, miou_r, per_r = R.worst_case(ref_i, ref_u, valid)
+    acc_d, miou_d, per_d = R.worst_case(dev_i, dev_u, valid)
+    # ---- aAcc: paired per-image differences of the worst-case accuracy (points)
+    diff = (per_d - per_r).double()
+    d_acc, sd = diff.mean().item(), diff.std(unbiased=True).item()
+    ci_acc = 1.96 * sd / n ** 0.5
+    # ---- mIoU: dataset-level statistic -> paired bootstrap over images (same resample for both sides)
+    rng = np.random.default_rng(225)
+    boots = []
+    for _ in range(200):
+        idx = torch.from_numpy(rng.integers(0, n, n))
+        _, mr, _ = R.worst_case(ref_i[:, idx], ref_u[:, idx], valid)
+        _, md, _ = R.worst_case(dev_i[:, idx], dev_u[:, idx], valid)
+        boots.append(md - mr)
+    d_miou = miou_d - miou_r
+    lo, hi = np.percentile(boots, [2.5, 97.5])
+    ci_miou = max(hi - d_miou, d_miou - lo, 0.0)
+    print(f"\n[SEA vs the real reference] eps {eps255}/255, {n} images of {R.SIZE}^2, 3 x 100 iterations\n"
+          f"  worst-case aAcc  reference {acc_r:8.4f} %   device {acc_d:8.4f} %   paired mean diff {d_acc:+.4f} points, "
+          f"per-image sd {sd:.3f}, 95 % CI half-width {ci_acc:.4f}\n"
+          f"  worst-case mIoU  reference {miou_r:8.4f} %   device {miou_d:8.4f} %   diff {d_miou:+.4f} points, "
+          f"paired bootstrap 95 % interval [{lo:+.4f}, {hi:+.4f}]")
+    assert 1.0 < miou_r < 60.0 and 1.0 < acc_r < 90.0           # the attack bites and the metrics are not degenerate
+    assert abs(d_acc) <= max(0.05, ci_acc), (d_acc, ci_acc)
+    assert abs(d_miou) <= max(0.05, ci_miou), (d_miou, ci_miou)

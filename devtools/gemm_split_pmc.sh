@@ -1,22 +1,32 @@
 #!/bin/bash
-# PMC passes over one split-GEMM shape (separate runs per counter group, kernel-trace only: gpurun rules)
+# PMC passes over one split-GEMM shape (separate runs per counter group, no tracing besides the counters: gpurun rules)
+#   bash devtools/gemm_split_pmc.sh G M K N terms
 cd ${GRAFT_REPO_ROOT:-.}; export TMPDIR=/tmp
 OUT=gpurun_out/gemm_pmc; rm -rf /tmp/gp; mkdir -p $OUT /tmp/gp
-rocprofv3 --list-avail 2>/dev/null | grep -o "\b\(SQ_[A-Z_0-9]*\|TCC_[A-Za-z_0-9]*\|TCP_[A-Za-z_0-9]*\|TA_[A-Z_0-9]*\|GRBM_[A-Z_0-9]*\)\b" | sort -u > $OUT/counters.txt
-wc -l $OUT/counters.txt
+echo "== $* SEA_GEMM_WIDE=${SEA_GEMM_WIDE:-1}" >> $OUT/summary.txt
 i=0
-for grp in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" "FETCH_SIZE WRITE_SIZE" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TA_BUSY_avr"; do
+for grp in "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d /tmp/gp/$i -- python3 devtools/gemm_split_case.py "$@" > /tmp/gp/log$i.txt 2>&1 || tail -3 /tmp/gp/log$i.txt
+  timeout 120 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/gp/$i -- python3 devtools/gemm_split_case.py "$@" > /tmp/gp/log$i.txt 2>&1 || tail -3 /tmp/gp/log$i.txt
   f=$(ls /tmp/gp/$i/*/*counter_collection.csv 2>/dev/null | head -1)
-  [ -n "$f" ] && python3 - "$f" <<'PY' >> $OUT/summary.txt
+  k=$(ls /tmp/gp/$i/*/*kernel_trace.csv 2>/dev/null | head -1)
+  [ -n "$f" ] && python3 - "$f" "$k" <<'PY' >> $OUT/summary.txt
 import csv, sys, collections
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
-    if "gemm_split_kernel" in r["Kernel_Name"]:
+    if "gemm_split" in r["Kernel_Name"] and "pack" not in r["Kernel_Name"]:
         acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+dur = [ (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(sys.argv[2])) if "gemm_split" in r["Kernel_Name"] and "pack" not in r["Kernel_Name"]] if len(sys.argv) > 2 and sys.argv[2] else []
+d = sum(dur) / len(dur) if dur else float("nan")
+print(f"kernel duration (profiled) {d / 1e3:.1f} us")
 for k, v in acc.items():
-    print(f"{k:36s} per launch {sum(v) / len(v):.4e}   ({len(v)} launches)")
+    m = sum(v) / len(v)
+    extra = ""
+    if k == "GRBM_GUI_ACTIVE":
+        extra = f"  -> clock {m / 8 / d:.2f} GHz"
+    if k == "SQ_VALU_MFMA_BUSY_CYCLES":
+        extra = f"  -> per SIMD {m / 1024:.0f} cycles"
+    print(f"{k:36s} per launch {m:.4e}{extra}")
 PY
 done
 cat $OUT/summary.txt

@@ -102,7 +102,7 @@ def main():
                     f"{100 * sum(v[0] for v in sea.values()) / tot:.3f} |\n")
             f.write("\n## top kernels (model forward / input-gradient backward: MIOpen, CK, hipBLASLt, ATen)\n\n"
                     "| ms/step | calls/step | % | kernel |\n|---|---|---|---|\n")
-            for n, (d, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:30]:
+            for n, (d, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:45]:
                 f.write(f"| {d / steps / 1e6:.3f} | {c / steps:.1f} | {100 * d / tot:.1f} | `{short(n)}` |\n")
 
     if a.kernels:

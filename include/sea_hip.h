@@ -178,6 +178,18 @@ int sea_apgd_track(const float* loss_sum, const float* track_sum, const int32_t*
                    int early_stop, int init, int32_t* acc_cnt, float* acc, float* loss_best,
                    float* loss_best_last, float* reduced_last, float* step, float* loss_steps,
                    uint8_t* flags, int32_t* done, const void* loss_workspace, void* stream);
+/* Replayable forms for a caller that captures one loop iteration in a HIP graph (every per-iteration scalar in device
+ * memory, fixed buffer addresses):
+ *   sea_apgd_linf_step_graph: K1 IN PLACE (x_old <- x_adv, x_adv <- new iterate); a = 1 when *iter_dev == 0, else 0.75.
+ *   sea_apgd_track_graph:     K7 (init = 0) with iter = *iter_dev and check_k = check_table[iter] (n_iter int32 entries,
+ *                             0 = no checkpoint); advances *iter_dev by one at its end. */
+int sea_apgd_linf_step_graph(const float* x, float* x_adv, float* x_old, const float* grad, const float* step_b,
+                             float eps, const int32_t* iter_dev, int B, int64_t n_per_img, void* stream);
+int sea_apgd_track_graph(const float* loss_sum, const float* track_sum, const int32_t* n_correct,
+                         const int32_t* n_ignored, int B, int64_t HW, int32_t* iter_dev, const int32_t* check_table,
+                         int n_iter, int early_stop, int32_t* acc_cnt, float* acc, float* loss_best,
+                         float* loss_best_last, float* reduced_last, float* step, float* loss_steps, uint8_t* flags,
+                         int32_t* done, const void* loss_workspace, void* stream);
 int sea_select_copy(const uint8_t* flags, float* x_adv, float* grad, float* x_best,
                     float* grad_best, float* x_best_adv, const void* pred, void* pred_best,
                     int pred_bytes, int B, int64_t n_per_img, int64_t HW, void* stream);

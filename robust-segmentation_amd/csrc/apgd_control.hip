@@ -21,7 +21,14 @@ __global__ __launch_bounds__(256) void apgd_track_kernel(
     int init, int32_t* __restrict__ acc_cnt, float* __restrict__ acc, float* __restrict__ loss_best,
     float* __restrict__ loss_best_last, float* __restrict__ reduced_last, float* __restrict__ step,
     float* __restrict__ loss_steps, uint8_t* __restrict__ flags, int32_t* __restrict__ done,
-    const LossRecord* __restrict__ records) {
+    const LossRecord* __restrict__ records, int32_t* __restrict__ iter_dev, const int32_t* __restrict__ check_table) {
+  // replayable form (HIP-graph mode): the loop index lives in *iter_dev, the checkpoint window of iteration i in
+  // check_table[i]; the counter is advanced at the very end, after every use (K1 of this step has read it already)
+  if (iter_dev != nullptr) {
+    iter = *iter_dev;
+    iter = iter < 0 ? 0 : (iter >= n_iter ? n_iter - 1 : iter);
+    check_k = check_table[iter];
+  }
   __shared__ int s_any_nonzero;
   __shared__ float s_track[1024];
   __shared__ int s_corr[1024];
@@ -118,6 +125,7 @@ __global__ __launch_bounds__(256) void apgd_track_kernel(
   // early stop: every image has zero pixel accuracy (attacker.py:568-569).  Not evaluated at
   // step 0: the reference only tests inside the loop.
   if (threadIdx.x == 0 && !frozen && early_stop && !init && s_any_nonzero == 0) *done = 1;
+  if (threadIdx.x == 0 && iter_dev != nullptr) *iter_dev = iter + 1;
 }
 
 // one image per blockIdx.y; flags are wave-uniform scalars
@@ -213,7 +221,25 @@ extern "C" int sea_apgd_track(const float* loss_sum, const float* track_sum, con
   hipLaunchKernelGGL(apgd_track_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_sum, track_sum, n_correct,
                      n_ignored, B, HW, iter, n_iter, check_k, early_stop, init, acc_cnt, acc, loss_best,
                      loss_best_last, reduced_last, step, loss_steps, flags, done,
-                     (track_sum && n_correct) ? (const LossRecord*)nullptr : (const LossRecord*)loss_workspace);
+                     (track_sum && n_correct) ? (const LossRecord*)nullptr : (const LossRecord*)loss_workspace,
+                     (int32_t*)nullptr, (const int32_t*)nullptr);
+  SEA_RETURN_LAST();
+}
+
+extern "C" int sea_apgd_track_graph(const float* loss_sum, const float* track_sum, const int32_t* n_correct,
+                                    const int32_t* n_ignored, int B, int64_t HW, int32_t* iter_dev,
+                                    const int32_t* check_table, int n_iter, int early_stop, int32_t* acc_cnt, float* acc,
+                                    float* loss_best, float* loss_best_last, float* reduced_last, float* step,
+                                    float* loss_steps, uint8_t* flags, int32_t* done, const void* loss_workspace,
+                                    void* stream) {
+  SEA_CHECK_ARG(acc_cnt && acc && loss_best && loss_best_last && reduced_last && step && flags && done && B > 0 &&
+                HW > 0 && iter_dev && check_table && n_ignored && loss_steps && n_iter > 0);
+  SEA_CHECK_ARG((track_sum && n_correct) || (loss_workspace && B <= 1024));
+  hipLaunchKernelGGL(apgd_track_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_sum, track_sum, n_correct,
+                     n_ignored, B, HW, 0, n_iter, 0, early_stop, 0, acc_cnt, acc, loss_best, loss_best_last, reduced_last,
+                     step, loss_steps, flags, done,
+                     (track_sum && n_correct) ? (const LossRecord*)nullptr : (const LossRecord*)loss_workspace, iter_dev,
+                     check_table);
   SEA_RETURN_LAST();
 }
 

@@ -79,6 +79,28 @@ __global__ __launch_bounds__(256) void apgd_linf_step_v1(const float* __restrict
     out[base + i] = apgd_elem(x[base + i], xadv[base + i], xold[base + i], grad[base + i], st, eps, a, oma);
 }
 
+// Replayable form of K1 (HIP-graph mode of the attack loop): every per-iteration scalar comes from device memory and
+// the iterate buffers keep their addresses.  *iter_dev is the loop index i (a = 1 for i = 0, else 0.75; K7 advances it);
+// the update is IN PLACE: x_old <- x_adv (the reference's `x_adv_old = x_adv.clone()`, attacker.py:390) and
+// x_adv <- new iterate, element by element (each element is read before it is written, by the same lane).
+__global__ __launch_bounds__(256) void apgd_linf_step_inplace_v4(const f4* __restrict__ x, f4* __restrict__ xadv,
+                                                                 f4* __restrict__ xold, const f4* __restrict__ grad,
+                                                                 const float* __restrict__ step_b, float eps,
+                                                                 const int32_t* __restrict__ iter_dev,
+                                                                 int64_t n4_per_img) {
+  const int b = blockIdx.y;
+  const float st = step_b[b];
+  const bool first = *iter_dev <= 0;
+  const float a = first ? 1.0f : 0.75f;
+  const float oma = first ? (float)(1.0 - 1.0) : (float)(1.0 - 0.75);  // (1 - a) in double, like the reference
+  const int64_t base = (int64_t)b * n4_per_img;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4_per_img; i += (int64_t)gridDim.x * blockDim.x) {
+    const f4 vx = x[base + i], va = xadv[base + i], vo = xold[base + i], vg = __builtin_nontemporal_load(grad + base + i);
+    xold[base + i] = va;
+    xadv[base + i] = apgd_elem4(vx, va, vo, vg, st, eps, a, oma);
+  }
+}
+
 // generic 2-input -> 1-output element-wise kernels, OP selected at compile time
 enum { OP_RANDOM_START = 0, OP_PROJECT = 1 };
 
@@ -197,6 +219,21 @@ extern "C" int sea_apgd_linf_step(const float* x, const float* x_adv, const floa
     hipLaunchKernelGGL(apgd_linf_step_v1, dim3(gx, B), dim3(256), 0, s, x, x_adv, x_old, grad, step_b, eps,
                        a, oma, out, n_per_img);
   }
+  SEA_RETURN_LAST();
+}
+
+extern "C" int sea_apgd_linf_step_graph(const float* x, float* x_adv, float* x_old, const float* grad,
+                                        const float* step_b, float eps, const int32_t* iter_dev, int B,
+                                        int64_t n_per_img, void* stream) {
+  SEA_CHECK_ARG(x && x_adv && x_old && grad && step_b && iter_dev && B > 0 && n_per_img > 0 && B <= 65535);
+  SEA_CHECK_ARG((n_per_img % 4) == 0 && aligned16(x) && aligned16(x_adv) && aligned16(x_old) && aligned16(grad));
+  const int64_t n4 = n_per_img / 4;
+  int gx = grid_for(n4, 256);
+  int cap = kMaxGridX / B;
+  if (cap < 1) cap = 1;
+  if (gx > cap) gx = cap;
+  hipLaunchKernelGGL(apgd_linf_step_inplace_v4, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, (const f4*)x, (f4*)x_adv,
+                     (f4*)x_old, (const f4*)grad, step_b, eps, iter_dev, n4);
   SEA_RETURN_LAST();
 }
 

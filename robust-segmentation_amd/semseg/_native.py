@@ -42,6 +42,9 @@ _SIGS = {
     "sea_confusion": (_i, [_vp, _i, _vp, _i, _i64, _i, _vp, _vp]),
     "sea_apgd_track": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                             _vp, _vp, _vp, _vp]),
+    "sea_apgd_linf_step_graph": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i64, _vp]),
+    "sea_apgd_track_graph": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                  _vp, _vp, _vp]),
     "sea_select_copy": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _vp]),
     "sea_count_ignored": (_i, [_vp, _i, _i, _i64, _vp, _vp]),
     "sea_worst_miou_greedy": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
@@ -313,6 +316,25 @@ def apgd_track(stats, n_ignored, HW: int, it: int, n_iter: int, check_k: int, ea
                                 _p(st.acc_cnt), _p(st.acc), _p(st.loss_best), _p(st.loss_best_last),
                                 _p(st.reduced_last), _p(st.step), _p(st.loss_steps), _p(st.flags), _p(st.done),
                                 _p(stats.get("workspace")), _stream()), "sea_apgd_track")
+
+
+def apgd_linf_step_graph(x, x_adv, x_old, grad, step_b, eps: float, iter_dev):
+    """K1 in place with the loop index read from device memory (HIP-graph mode): x_old <- x_adv, x_adv <- new."""
+    _dev(x, x_adv, x_old, grad, step_b, iter_dev)
+    for t in (x, x_adv, x_old, grad):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise SeaNativeError("apgd_linf_step_graph: contiguous float32 buffers expected")
+    _check(lib().sea_apgd_linf_step_graph(_p(x), _p(x_adv), _p(x_old), _p(grad), _p(_f32c(step_b)), eps, _p(iter_dev),
+                                          x.shape[0], x[0].numel(), _stream()), "sea_apgd_linf_step_graph")
+
+
+def apgd_track_graph(stats, n_ignored, HW: int, iter_dev, check_table, n_iter: int, early_stop: bool, st):
+    """K7 with the loop index and the checkpoint schedule in device memory; advances ``iter_dev``."""
+    _check(lib().sea_apgd_track_graph(_p(stats["loss_sum"]), _p(stats["track_sum"]), _p(stats["n_correct"]),
+                                      _p(n_ignored), st.B, HW, _p(iter_dev), _p(check_table), n_iter, int(early_stop),
+                                      _p(st.acc_cnt), _p(st.acc), _p(st.loss_best), _p(st.loss_best_last),
+                                      _p(st.reduced_last), _p(st.step), _p(st.loss_steps), _p(st.flags), _p(st.done),
+                                      _p(stats.get("workspace")), _stream()), "sea_apgd_track_graph")
 
 
 def select_copy(flags, x_adv, grad, x_best, grad_best, x_best_adv, pred=None, pred_best=None):

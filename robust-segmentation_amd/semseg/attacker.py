@@ -23,6 +23,8 @@ from __future__ import annotations
 
 from functools import partial
 
+import os
+
 import torch
 
 from . import _native as N
@@ -282,6 +284,10 @@ def _input_grad(logits, x_in, dlogits):
 FUSE_UPSAMPLE = "auto"
 FUSE_UPSAMPLE_AUTO_BYTES = 24 * 2 ** 30
 
+# HIP-graph replay of the middle iterations of an APGD run (see ApgdRun._capture).  SEA_HIP_GRAPH=0 disables it.
+USE_HIP_GRAPH = os.environ.get("SEA_HIP_GRAPH", "1") != "0"
+GRAPH_MIN_ITER = 12
+
 
 class ApgdRun:
     """One APGD run as an object: ``start()`` is step 0 (reference lines 342-383), ``step(i)`` is loop
@@ -333,6 +339,8 @@ class ApgdRun:
         self.ws_low = None
         self.last = None       # K2 outputs of the latest iterate
         self.k2_events = None  # optional list of (start, end) event pairs, one per step (bench.py)
+        self.use_graph = USE_HIP_GRAPH and n_iter >= GRAPH_MIN_ITER   # capture costs ~3 eager iterations
+        self.graphs = None
 
     def _loss(self, logits, want_grad):
         ev = None
@@ -373,6 +381,22 @@ class ApgdRun:
         self.x_next = torch.empty_like(self.x_adv)
 
     def step(self, i: int):
+        if self.use_graph and not self.fused and self.n_iter > 3:
+            if 2 <= i < self.n_iter - 1:
+                return self._step_graph(i)
+            if i == 1:
+                # eager, but on the stream the graphs will be captured on: per-stream library state (MIOpen / hipBLASLt
+                # handles and workspaces) must exist before a capture starts
+                self._gs = torch.cuda.Stream()
+                cur = torch.cuda.current_stream()
+                self._gs.wait_stream(cur)
+                with torch.cuda.stream(self._gs):
+                    self._step_eager(i)
+                cur.wait_stream(self._gs)
+                return
+        self._step_eager(i)
+
+    def _step_eager(self, i: int):
         # ---- gradient step (reference lines 389-456): K1, then rotate the three iterate buffers
         a = 0.75 if i > 0 else 1.0
         N.apgd_linf_step(self.x, self.x_adv, self.x_old, self.grad, self.st.step, self.eps, a, out=self.x_next)
@@ -388,6 +412,46 @@ class ApgdRun:
         N.apgd_track(r, self.n_ignored, self.HW, i, self.n_iter, self.cps.get(i, 0), self.early_stop, False, self.st)
         N.select_copy(self.st.flags, self.x_adv, self.grad, self.x_best, self.grad_best, self.x_best_adv, self.pred,
                       self.pred_best)
+
+    # ---- HIP-graph mode ----------------------------------------------------------------------------------------
+    # An iteration is ~360 kernel launches that the host needs 9-14 ms to enqueue (ConvNeXt-T, B=8) for 22 ms of GPU
+    # work: hidden on one GPU, not with 8 ranks on one host or a faster model side.  With `use_graph` the middle
+    # iterations (2 <= i < n_iter - 1) are replays of TWO captured graphs around the one eager K2 launch:
+    #     graph A = K1 (in place, `a` from the device-side loop index) + model forward
+    #     K2      = eager (so a caller can still bracket it with events; bench.py does)
+    #     graph B = input-gradient backward + K7 (loop index / checkpoint window from device memory) + K4
+    # Iterations 0 and 1 run eagerly (library warm-up on the capture stream), the last one too (no backward there).
+    # Same kernels, same arithmetic, same order: the outputs are bitwise those of the eager loop (tested).
+    def _graph_ready(self):
+        return self.graphs is not None
+
+    def _capture(self, i: int):
+        dev = self.x.device
+        self.it_dev = torch.full((1,), i, dtype=torch.int32, device=dev)
+        tab = [self.cps.get(k, 0) for k in range(max(self.n_iter, 1))]
+        self.cp_dev = torch.tensor(tab, dtype=torch.int32, device=dev)
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga, stream=self._gs):
+            N.apgd_linf_step_graph(self.x, self.x_adv, self.x_old, self.grad, self.st.step, self.eps, self.it_dev)
+            self._g_xin, self._g_logits = _forward_logits(self.model, self.x_adv, True, self.fused)
+        ga.replay()
+        r = self._loss(self._g_logits, True)          # eager, and it defines the (persistent) K2 output buffers
+        with torch.cuda.graph(gb, pool=ga.pool(), stream=self._gs):
+            g = _input_grad(self._g_logits, self._g_xin, r["dlogits"])
+            self.grad.copy_(g)                           # the gradient buffer keeps its address (K1 / K4 read it)
+            N.apgd_track_graph(r, self.n_ignored, self.HW, self.it_dev, self.cp_dev, self.n_iter, self.early_stop, self.st)
+            N.select_copy(self.st.flags, self.x_adv, self.grad, self.x_best, self.grad_best, self.x_best_adv, self.pred,
+                          self.pred_best)
+        gb.replay()
+        self.graphs = (ga, gb)
+
+    def _step_graph(self, i: int):
+        if self.graphs is None:
+            self._capture(i)                              # captures AND performs iteration i
+            return
+        self.graphs[0].replay()
+        self._loss(self._g_logits, True)
+        self.graphs[1].replay()
 
     def result(self):
         return self.x_best, self.st.acc, self.st.loss_best, self.x_best_adv

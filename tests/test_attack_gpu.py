@@ -185,3 +185,37 @@ def test_pgd_attack_under_bf16_autocast():
         acc0 = (net(x).max(1)[1] == y).float().mean()
         acc1 = (net(x_adv).max(1)[1] == y).float().mean()
     assert acc1 < acc0
+
+
+@pytest.mark.parametrize("loss", ["mask-ce-bal", "js-avg"])
+def test_hip_graph_replay_is_bitwise_the_eager_loop(loss):
+    """ApgdRun's HIP-graph mode (two captured graphs around the eager K2 launch, loop index and checkpoint schedule in
+    device memory, K1 in place) against the eager loop on the real UperNet-ConvNeXt-T: same kernels, same order ->
+    every output identical bit for bit, including runs with step-size halvings, restarts from the best point and the
+    early-stop freeze."""
+    from semseg import attacker as A
+    from semseg.models import UperNetForSemanticSegmentation
+    from semseg.utils.utils import VOC_WTS
+    torch.manual_seed(0)
+    model = UperNetForSemanticSegmentation("ConvNeXt-T_CVST", 21, None).eval().cuda()
+    # 512 x 512: the size at which every kernel of the model path is bitwise reproducible (smaller maps send the PSP
+    # bottleneck to a MIOpen kernel that accumulates with atomics, DESIGN 4b)
+    x = torch.rand(2, 3, 512, 512, generator=torch.Generator().manual_seed(5)).cuda()
+    with torch.no_grad():
+        y = model(x).max(1)[1]
+    y[0, :4] = -1                                               # some ignored pixels
+    w = torch.tensor(VOC_WTS).cuda()
+    noise = torch.rand(x.shape, generator=torch.Generator().manual_seed(6)).cuda()
+    outs = []
+    for graph in (False, True, False):
+        old, A.USE_HIP_GRAPH = A.USE_HIP_GRAPH, graph
+        try:
+            outs.append(A.apgd_train(model, x, y, "Linf", 8.0 / 255, n_iter=30, use_rs=True, loss=loss, early_stop=True,
+                                     track_loss="ce-avg", num_classes=21, weights=w, noise=noise, return_pred=True))
+        finally:
+            A.USE_HIP_GRAPH = old
+    for a, c in zip(outs[0], outs[2]):
+        assert torch.equal(a, c), "the eager loop itself is not reproducible here"
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    assert (outs[0][3] - x).abs().max() <= 8.0 / 255 + 1e-6

@@ -105,3 +105,22 @@ def test_shard_indices_cover_everything_once():
         for w in (1, 2, 3, 8):
             got = sorted(i for r in range(w) for i in shard_indices(n, r, w))
             assert got == list(range(n))
+
+
+def test_sharded_stats_ade_size_two_ranks_equal_one_rank(tmp_path):
+    """BASELINE configs[4]'s table size: C = 151 (ADE20K), a ragged 11 images over 2 ranks, ignore labels present.
+    The packed int64 buffer (one all-reduce) merged over gloo equals the single-process buffer bit for bit."""
+    from tools.sea_shard import SeaStats, shard_indices
+    C, n = 151, 11
+    g = torch.Generator().manual_seed(151)
+    tgt = torch.randint(0, C, (n, 24, 20), generator=g)
+    tgt[torch.rand(tgt.shape, generator=g) < 0.07] = -1
+    preds = torch.where(torch.rand(3, n, 24, 20, generator=g) < 0.6, tgt.unsqueeze(0).clamp_min(0),
+                        torch.randint(0, C, (3, n, 24, 20), generator=g))
+    single = SeaStats(3, n, C)
+    _local_fill(single, shard_indices(n, 0, 1), preds, tgt, C)
+    out = str(tmp_path / "buf151.pt")
+    mp.spawn(_worker, args=(2, _free_port(), preds, tgt, C, out), nprocs=2, join=True)
+    merged = torch.load(out)
+    assert merged.dtype == torch.int64 and torch.equal(merged, single.buf)
+    assert merged.numel() >= 2 * 3 * n * C                      # the per-image (A,N,C) inter / union tables travel in it

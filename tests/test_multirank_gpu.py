@@ -36,24 +36,30 @@ def _torchrun(n, module_args, cwd=PKG, extra_env=None, timeout=1500):
     return r
 
 
-def _cfg(tmp_path, name, **train):
+def _cfg(tmp_path, name, backbone=None, **train):
     import yaml
     cfg = yaml.safe_load(open(os.path.join(PKG, "configs", name)))
     cfg["SAVE_DIR"] = str(tmp_path) + "/"
     cfg["TRAIN"].update(train)
+    if backbone is not None:
+        cfg["MODEL"]["BACKBONE"] = cfg["EVAL"]["BACKBONE"] = backbone
     p = str(tmp_path / "cfg.yaml")
     yaml.safe_dump(cfg, open(p, "w"))
     return p
 
 
-def test_sharded_sea_eval_two_ranks_equal_one_rank(tmp_path):
+@pytest.mark.parametrize("name,backbone,n_img,n_iter", [
+    ("pascalvoc_convnext.yaml", None, 8, 10),                     # configs[1]: UperNet-ConvNeXt-T, C=21
+    ("ade20k_convnext.yaml", "ConvNeXt-S_CVST", 4, 5),            # configs[4]: UperNet-ConvNeXt-S, C=151 (class-split K2,
+])                                                                #             the 32x larger packed statistics buffer)
+def test_sharded_sea_eval_two_ranks_equal_one_rank(tmp_path, name, backbone, n_img, n_iter):
     from tools import infer
-    cfg = _cfg(tmp_path, "pascalvoc_convnext.yaml")
+    cfg = _cfg(tmp_path, name, backbone)
     # 8 images, batches of 2: 4 batches on one rank, 2 + 2 on two (equal batch SIZES: hipBLASLt picks its GEMM kernel
     # by shape, and a different kernel rounds differently).  512x512: every layer of the model then runs a bitwise reproducible kernel (own kernels + hipBLASLt GEMMs; MIOpen
     # only serves the stem), and the random starts are per-image streams, so the sharding cannot change a single count
-    common = ["--cfg", cfg, "--eps", "8", "--n_iter", "10", "--synthetic", "8", "--image_size", "512", "--batch_size", "2",
-              "--cleanup", "0", "--deterministic"]
+    common = ["--cfg", cfg, "--eps", "8", "--n_iter", str(n_iter), "--synthetic", str(n_img), "--image_size", "512",
+              "--batch_size", "2", "--cleanup", "0", "--deterministic"]
     one = str(tmp_path / "one.pt")
     s1 = infer.main(common + ["--dump_stats", one])
     two, js = str(tmp_path / "two.pt"), str(tmp_path / "two.json")
@@ -61,20 +67,23 @@ def test_sharded_sea_eval_two_ranks_equal_one_rank(tmp_path):
     a, b = torch.load(one), torch.load(two)
     assert a.dtype == torch.int64 and torch.equal(a, b)          # integer tables: independent of the sharding
     s2 = json.load(open(js))
-    assert s2["world"] == 2 and s2["n_images"] == 8
+    assert s2["world"] == 2 and s2["n_images"] == n_img
     for k in ("worst_Acc", "final_miou", "loss-wise_miou", "clean"):
         assert s1[k] == s2[k], k
 
 
-@pytest.mark.parametrize("adversarial", [False, True])
-def test_ddp_two_ranks_equal_gradient_average_of_one_process(tmp_path, adversarial):
+@pytest.mark.parametrize("adversarial,name,backbone", [
+    (False, "pascalvoc_convnext.yaml", None), (True, "pascalvoc_convnext.yaml", None),
+    (True, "ade20k_convnext.yaml", "ConvNeXt-S_CVST"),          # configs[3]'s model and class count
+])
+def test_ddp_two_ranks_equal_gradient_average_of_one_process(tmp_path, adversarial, name, backbone):
     """One PIR-AT outer step (2-step inner PGD + forward/backward) on 2 DDP ranks: the gradients every rank holds after
     the bucketed all-reduce are the average of the two ranks' gradients, which one process reproduces by running both
     batches from the same weights and buffers (`--emulate_ranks 2`).  Gradients are compared, not AdamW-updated
     weights (m / sqrt(v) turns rounding noise of near-zero gradients into +-lr steps)."""
     # 512x512: the eval-mode inner attack then runs bitwise reproducible kernels only, so both set-ups train on the same
     # adversarial images; what remains are the atomics of MIOpen's weight-gradient kernels in the outer backward
-    cfg = _cfg(tmp_path, "pascalvoc_convnext.yaml", IMAGE_SIZE=[512, 512], N_ITERS=2, ADVERSARIAL=adversarial)
+    cfg = _cfg(tmp_path, name, backbone, IMAGE_SIZE=[512, 512], N_ITERS=2, ADVERSARIAL=adversarial)
     common = ["--cfg", cfg, "--synthetic", "2", "--steps", "1", "--warmup", "0", "--batch_size", "2", "--deterministic"]
     p2, j2 = str(tmp_path / "p2.pt"), str(tmp_path / "j2.json")
     _torchrun(2, ["-m", "tools.train_rob_seg"] + common + ["--backend", "gloo", "--dump_params", p2, "--json", j2])

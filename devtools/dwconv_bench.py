@@ -34,7 +34,6 @@ def timed(fn, n):
 
 
 def main():
-    os.environ["SEA_DWCONV_AB_LIVE"] = "1"      # before the library reads it
     B = 8
     for Cc, hw in ((96, 128), (192, 64), (384, 32), (768, 16)):
         nset = max(2, int(1.6e9 // (8 * B * hw * hw * Cc)))

@@ -237,12 +237,9 @@ __global__ __launch_bounds__(256, 2) void dwconv7x7_nhwc_2row_kernel(const float
 
 using namespace sea;
 
-// A/B switches of the NHWC depthwise launcher (development only; unset = shipped dispatch).  The variable is looked
-// up once per process unless SEA_DWCONV_AB_LIVE=1 asks for a lookup per call (the A/B bench flips it between launches).
+// A/B switches of the NHWC depthwise launcher (development only; unset = shipped dispatch).  Looked up per call (one
+// getenv, ~0.1 us next to a 5 us launch) so that one process can compare variants.
 static inline int dwconv_ab_switches() {
-  static const int live = [] { const char* e = getenv("SEA_DWCONV_AB_LIVE"); return (e && e[0] == '1') ? 1 : 0; }();
-  static const int cached = [] { const char* e = getenv("SEA_DWCONV_AB"); return e ? atoi(e) : 0; }();
-  if (!live) return cached;
   const char* e = getenv("SEA_DWCONV_AB");
   return e ? atoi(e) : 0;
 }

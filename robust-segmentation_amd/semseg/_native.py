@@ -543,10 +543,10 @@ def wino_conv3x3_cl(x, U, m: int, bias=None, scale=None, relu: bool = False, gat
         off += t.shape[1]
     if gemm_terms in (2, 3) and Cin % 32 == 0 and T >= 256:
         # M8: the (A*A) Winograd-domain products on the bf16 matrix cores (operands split into bf16 terms, fp32 accumulate)
-        Up = getattr(U, "_sea_packed", None)
-        if Up is None or Up.terms != gemm_terms:
-            Up = gemm_split_pack(U, trans=True, terms=gemm_terms)
-            U._sea_packed = Up                      # U is the cached, frozen filter image: packed once
+        packed = U.__dict__.setdefault("_sea_packed", {})   # U is the cached, frozen filter image: packed once per term count
+        Up = packed.get(gemm_terms)
+        if Up is None:
+            Up = packed[gemm_terms] = gemm_split_pack(U, trans=True, terms=gemm_terms)
         Mx = gemm_split(V, Up)
     else:
         with torch.autocast("cuda", enabled=False):

@@ -229,25 +229,48 @@ def _tkey(*ts):
 #      own GPU runs use by default)
 #   0: hipBLASLt fp32 (torch.mm / bmm / addmm), as in rounds 1-2
 GEMM_TERMS = int(os.environ.get("SEA_GEMM_TERMS", "3"))
+# Under bf16 autocast (PIR-AT's inner PGD with TRAIN.AMP, BASELINE configs[3]) the decode head's fp32 islands run M8 with
+# TWO terms: 16 significant bits per operand (twice bf16's) at three MFMA products instead of six.
+GEMM_TERMS_AUTOCAST = int(os.environ.get("SEA_GEMM_TERMS_AUTOCAST", "2"))
 GEMM_MIN_ROWS = 1024   # below, a 128-row tile grid cannot fill the chip: hipBLASLt's split-K kernels win
+_TERMS_OVERRIDE = [None]
 
 
-def _split_ok(x2d, K):
-    return (GEMM_TERMS in (2, 3) and x2d.is_cuda and x2d.dtype == torch.float32 and x2d.dim() == 2 and K % 32 == 0
+def _terms():
+    """number of bf16 terms M8 uses right now (a Function records it in forward and reuses it in backward)"""
+    return GEMM_TERMS if _TERMS_OVERRIDE[0] is None else _TERMS_OVERRIDE[0]
+
+
+class _gemm_terms:
+    def __init__(self, terms):
+        self.terms = terms
+
+    def __enter__(self):
+        self.old, _TERMS_OVERRIDE[0] = _TERMS_OVERRIDE[0], self.terms
+
+    def __exit__(self, *exc):
+        _TERMS_OVERRIDE[0] = self.old
+        return False
+
+
+def _split_ok(x2d, K, terms=None):
+    return ((_terms() if terms is None else terms) in (2, 3) and x2d.is_cuda and x2d.dtype == torch.float32 and x2d.dim() == 2 and K % 32 == 0
             and x2d.stride(1) == 1 and x2d.stride(0) % 4 == 0 and x2d.data_ptr() % 16 == 0
             and x2d.shape[0] >= GEMM_MIN_ROWS and not torch.is_autocast_enabled())
 
 
-def _frozen_mm(x2d, w, cache, name, trans=False, bias=None, relu=False):
+def _frozen_mm(x2d, w, cache, name, trans=False, bias=None, relu=False, terms=None):
     """act(x2d @ W^T + bias) for a FROZEN weight: w is (N, K), or (K, N) with ``trans``.  The packed (pre-split) image
-    of w is cached in ``cache`` under ``name`` until w changes."""
+    of w is cached in ``cache`` under ``name`` (per number of terms) until w changes."""
     K = w.shape[0] if trans else w.shape[1]
-    if _split_ok(x2d, K):
+    terms = _terms() if terms is None else terms
+    if _split_ok(x2d, K, terms):
         from .. import _native as N
-        key = (_tkey(w), GEMM_TERMS, trans)
+        name = f"{name}_t{terms}"
+        key = (_tkey(w), trans)
         if cache.get(name + "_key") != key:
             with torch.no_grad():
-                cache[name] = N.gemm_split_pack(w.detach(), trans=trans, terms=GEMM_TERMS)
+                cache[name] = N.gemm_split_pack(w.detach(), trans=trans, terms=terms)
             cache[name + "_key"] = key
         return N.gemm_split(x2d, cache[name], bias=bias, relu=relu)
     wt = w if trans else w.t()
@@ -261,7 +284,7 @@ class _FrozenLinear(torch.autograd.Function):
     @staticmethod
     @_fp32_fwd
     def forward(ctx, x, w, b, cache):
-        ctx.w, ctx.cache, ctx.shape = w, cache, x.shape
+        ctx.w, ctx.cache, ctx.shape, ctx.terms = w, cache, x.shape, _terms()
         x2 = x.reshape(-1, x.shape[-1])
         return _frozen_mm(x2, w, cache, "lin_fwd", bias=b).view(*x.shape[:-1], w.shape[0])
 
@@ -271,12 +294,12 @@ class _FrozenLinear(torch.autograd.Function):
         g2 = gy.reshape(-1, gy.shape[-1])
         if not g2.is_contiguous():
             g2 = g2.contiguous()
-        return _frozen_mm(g2, ctx.w, ctx.cache, "lin_bwd", trans=True).view(ctx.shape), None, None, None
+        return _frozen_mm(g2, ctx.w, ctx.cache, "lin_bwd", trans=True, terms=ctx.terms).view(ctx.shape), None, None, None
 
 
 def _linear_frozen(mod_cache, x, w, b):
     """F.linear through M8 when the weights are frozen and the shape qualifies; plain F.linear otherwise."""
-    if (GEMM_TERMS in (2, 3) and x.is_cuda and x.dtype == torch.float32 and not w.requires_grad
+    if (_terms() in (2, 3) and x.is_cuda and x.dtype == torch.float32 and not w.requires_grad
             and (b is None or not b.requires_grad) and w.shape[1] % 32 == 0 and not torch.is_autocast_enabled()
             and x.is_contiguous() and x.numel() // x.shape[-1] >= GEMM_MIN_ROWS):
         return _FrozenLinear.apply(x, w, b, mod_cache)
@@ -443,7 +466,7 @@ class _PatchConv2x2(torch.autograd.Function):
         else:
             patches = xn.reshape(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, 4 * C)
         y = _frozen_mm(patches, wr, cache, "patch_fwd", bias=bias)
-        ctx.wr, ctx.shape, ctx.cache = wr, (B, C, H, W), cache
+        ctx.wr, ctx.shape, ctx.cache, ctx.terms = wr, (B, C, H, W), cache, _terms()
         # under autocast the GEMM ran (and returned) bf16: the trunk's residual stream stays fp32
         return y.float().view(B, H // 2, W // 2, -1).permute(0, 3, 1, 2)       # channels_last (B,Cout,H/2,W/2)
 
@@ -451,7 +474,8 @@ class _PatchConv2x2(torch.autograd.Function):
     def backward(ctx, gy):
         B, C, H, W = ctx.shape
         g = gy.permute(0, 2, 3, 1).reshape(-1, gy.shape[1])
-        rows = _frozen_mm(g if g.is_contiguous() else g.contiguous(), ctx.wr, ctx.cache, "patch_bwd", trans=True).float()
+        rows = _frozen_mm(g if g.is_contiguous() else g.contiguous(), ctx.wr, ctx.cache, "patch_bwd", trans=True,
+                          terms=ctx.terms).float()
         if C % 4 == 0 and rows.is_contiguous():
             from .. import _native as N
             gp = N.unpatch2x2(rows, B, H, W)
@@ -542,8 +566,8 @@ class _WinoConv3x3(torch.autograd.Function):
         key = (_tkey(weight), m)
         if cache.get("key") != key:
             cache.update(key=key, fwd=N.wino_filter(weight.contiguous(), m, False), bwd=None)
-        ctx.cache, ctx.m, ctx.weight, ctx.relu = cache, m, weight, relu
-        y = N.wino_conv3x3_cl(_dense_cl(x), cache["fwd"], m, bias=shift, scale=scale, relu=relu, gemm_terms=GEMM_TERMS)
+        ctx.cache, ctx.m, ctx.weight, ctx.relu, ctx.terms = cache, m, weight, relu, _terms()
+        y = N.wino_conv3x3_cl(_dense_cl(x), cache["fwd"], m, bias=shift, scale=scale, relu=relu, gemm_terms=ctx.terms)
         if relu:
             ctx.save_for_backward(y, scale)
         return y
@@ -557,7 +581,7 @@ class _WinoConv3x3(torch.autograd.Function):
             cache["bwd"] = N.wino_filter(ctx.weight.contiguous(), ctx.m, True)
         gate, gscale = ctx.saved_tensors if ctx.relu else (None, None)
         g = gy if N.cl_pixel_stride(gy) is not None else gy.contiguous(memory_format=_CL)  # slices read in place
-        gx = N.wino_conv3x3_cl(g, cache["bwd"], ctx.m, gate=gate, gate_scale=gscale, gemm_terms=GEMM_TERMS)
+        gx = N.wino_conv3x3_cl(g, cache["bwd"], ctx.m, gate=gate, gate_scale=gscale, gemm_terms=ctx.terms)
         return gx, None, None, None, None, None, None
 
 
@@ -608,14 +632,14 @@ class _PointwiseRelu(torch.autograd.Function):
     def forward(ctx, x2, w, shift, cache):
         y = _frozen_mm(x2, w, cache, "pw_fwd", bias=shift, relu=True)
         ctx.save_for_backward(y)
-        ctx.w, ctx.cache = w, cache
+        ctx.w, ctx.cache, ctx.terms = w, cache, _terms()
         return y
 
     @staticmethod
     def backward(ctx, gy):
         (y,) = ctx.saved_tensors
         g = torch.where(y > 0, gy, torch.zeros((), dtype=gy.dtype, device=gy.device))
-        return _frozen_mm(g, ctx.w, ctx.cache, "pw_bwd", trans=True), None, None, None
+        return _frozen_mm(g, ctx.w, ctx.cache, "pw_bwd", trans=True, terms=ctx.terms), None, None, None
 
 
 class ConvModule(nn.Module):
@@ -828,8 +852,9 @@ class _FpnBottleneck(torch.autograd.Function):
             G = _frozen_mm(f.permute(0, 2, 3, 1).reshape(-1, f.shape[1]), cache["fpn_lo"][j], cache,
                            f"fpn_lo_fwd{j}").view(B, f.shape[2], f.shape[3], 9, Cout)
             extra = N.tap_gather(G, (H, W), extra)
+        ctx.terms = _terms()
         y = N.wino_conv3x3_cl(xs, cache["fpn_fwd"], m, bias=shift, scale=scale, relu=True, addend=extra,
-                              gemm_terms=GEMM_TERMS)
+                              gemm_terms=ctx.terms)
         ctx.save_for_backward(y, scale)
         ctx.cache, ctx.m, ctx.hi, ctx.lo, ctx.chans = cache, m, hi, lo, chans
         ctx.shapes = [tuple(f.shape) for f in fs]
@@ -845,7 +870,7 @@ class _FpnBottleneck(torch.autograd.Function):
         gz = N.gate_scale(_dense_cl(gy), y, scale)
         grads = [None] * len(shapes)
         if any(ctx.needs_input_grad[5 + i] for i in ctx.hi):
-            gbuf = N.wino_conv3x3_cl(gz, cache["fpn_bwd"], ctx.m, gemm_terms=GEMM_TERMS)
+            gbuf = N.wino_conv3x3_cl(gz, cache["fpn_bwd"], ctx.m, gemm_terms=ctx.terms)
             off = 0
             for i in ctx.hi:
                 sl = gbuf[:, off:off + chans[i]]
@@ -856,8 +881,8 @@ class _FpnBottleneck(torch.autograd.Function):
             if ctx.needs_input_grad[5 + i]:
                 h, w = shapes[i][2:]
                 dG = N.tap_gather_backward(gz, (h, w))
-                grads[i] = _frozen_mm(dG.view(B * h * w, -1), cache["fpn_lo"][j], cache, f"fpn_lo_bwd{j}", trans=True
-                                      ).view(B, h, w, chans[i]).permute(0, 3, 1, 2)
+                grads[i] = _frozen_mm(dG.view(B * h * w, -1), cache["fpn_lo"][j], cache, f"fpn_lo_bwd{j}", trans=True,
+                                      terms=ctx.terms).view(B, h, w, chans[i]).permute(0, 3, 1, 2)
         return (None, None, None, None, None, *grads)
 
 
@@ -1000,9 +1025,10 @@ class UperNetForSemanticSegmentation(nn.Module):
         """Decode head.  Under autocast with FROZEN weights (the attack's forward: PIR-AT's inner PGD with TRAIN.AMP,
         BASELINE configs[3]) the head runs with autocast switched off: its fp32 fast paths (Winograd-domain 3x3
         convolutions at a quarter of the multiplications, NHWC upsample / concat kernels, folded-BatchNorm GEMMs) beat
-        the bf16 library composition, while the trunk keeps autocast and runs its MLP GEMMs in bf16."""
+        the bf16 library composition, while the trunk keeps autocast and runs its MLP GEMMs in bf16.  The islands' GEMMs
+        run M8 with two bf16 terms there (16 significant bits per operand, three MFMA products)."""
         if torch.is_autocast_enabled() and feats[0].dtype == torch.float32 and not self.decode_head.classifier.weight.requires_grad:
-            with torch.autocast("cuda", enabled=False):
+            with torch.autocast("cuda", enabled=False), _gemm_terms(GEMM_TERMS_AUTOCAST if GEMM_TERMS else 0):
                 return self.decode_head(feats)
         return self.decode_head(feats)
 

@@ -17,7 +17,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .convnext_upernet import StochasticDepth, _fp32_bwd, _fp32_fwd, _layer_norm, _up
+from .convnext_upernet import StochasticDepth, _fp32_bwd, _fp32_fwd, _layer_norm, _linear_frozen, _up
 
 
 def _init(m):
@@ -76,12 +76,14 @@ class Attention(nn.Module):
 
     def forward(self, x):
         B, T, D = x.shape
-        qkv = self.qkv(x)
+        # frozen weights (the attack's forward): M8 split-bf16 GEMMs, forward and input gradient; plain F.linear otherwise
+        gc = self.__dict__.setdefault("_gemm_cache", ({}, {}))
+        qkv = _linear_frozen(gc[0], x, self.qkv.weight, self.qkv.bias)
         p = self.attn_drop.p if self.training else 0.0
         if (USE_HIP_ATTENTION and p == 0.0 and qkv.is_cuda and qkv.dtype == torch.float32 and D // self.heads == 64
                 and qkv.is_contiguous()):
             y = _AttentionHip.apply(qkv.view(B, T, 3, self.heads, 64), self.scale)
-            return self.proj_drop(self.proj(y))
+            return self.proj_drop(_linear_frozen(gc[1], y, self.proj.weight, self.proj.bias))
         q, k, v = qkv.reshape(B, T, 3, self.heads, D // self.heads).permute(2, 0, 3, 1, 4)
         y = F.scaled_dot_product_attention(q, k, v, dropout_p=p, scale=self.scale)
         return self.proj_drop(self.proj(y.transpose(1, 2).reshape(B, T, D)))
@@ -96,7 +98,9 @@ class FeedForward(nn.Module):
         self.drop = nn.Dropout(dropout)
 
     def forward(self, x):
-        return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+        gc = self.__dict__.setdefault("_gemm_cache", ({}, {}))
+        h = self.drop(self.act(_linear_frozen(gc[0], x, self.fc1.weight, self.fc1.bias)))
+        return self.drop(_linear_frozen(gc[1], h, self.fc2.weight, self.fc2.bias))
 
 
 class Block(nn.Module):
@@ -125,6 +129,14 @@ class PatchEmbedding(nn.Module):
         self.proj = nn.Conv2d(channels, embed_dim, kernel_size=patch_size, stride=patch_size)
 
     def forward(self, im):
+        """The stride-P PxP convolution (vit_encoder.py:135-150) as ONE GEMM on the non-overlapping patches: same
+        arithmetic, but a hipBLASLt GEMM instead of a MIOpen convolution: bitwise reproducible, and no MIOpen kernel is
+        JIT-compiled per (batch, image size) on a fresh box (140 s each, measured in the GPU test run)."""
+        B, C, H, W = im.shape
+        P = self.patch_size
+        if im.is_cuda and H % P == 0 and W % P == 0 and self.proj.groups == 1:
+            patches = im.reshape(B, C, H // P, P, W // P, P).permute(0, 2, 4, 1, 3, 5).reshape(B, (H // P) * (W // P), C * P * P)
+            return F.linear(patches, self.proj.weight.reshape(self.proj.weight.shape[0], -1), self.proj.bias)
         return self.proj(im).flatten(2).transpose(1, 2)
 
 

@@ -820,14 +820,20 @@ def test_dwconv7x7_nhwc_forward_and_backward_data(N, shape):
     skip = dev(torch.randn(gyn.shape, generator=g))
     # fused skip-gradient add: bitwise the separate element-wise add, in both kernel variants
     assert torch.equal(N.dwconv7x7_nhwc(gyn, dev(wt), None, flip=True, addend=skip), gx + skip)
-    assert torch.equal(N.dwconv7x7_nhwc(gyn, dev(wt), None, flip=5, addend=skip), gx + skip)
-    assert torch.equal(N.dwconv7x7_nhwc(gyn, dev(wt), None, flip=9, addend=skip), gx + skip)
-    assert torch.equal(N.dwconv7x7_nhwc(xn, dev(wt), None, flip=0, addend=skip), N.dwconv7x7_nhwc(xn, dev(wt), None) + skip)
+    assert torch.equal(N.dwconv7x7_nhwc(xn, dev(wt), None, flip=False, addend=skip), N.dwconv7x7_nhwc(xn, dev(wt), None) + skip)
+    assert torch.equal(N.dwconv7x7_nhwc(gyn, dev(wt), None, flip=2, addend=skip), gx + skip)   # `flip` is a boolean
     with pytest.raises(N.SeaNativeError):
         N.dwconv7x7_nhwc(xn, dev(wt), dev(b), addend=skip)  # bias and addend are mutually exclusive
-    for bits in (2, 4, 6, 8, 10):
-        assert torch.equal(y, N.dwconv7x7_nhwc(xn, dev(wt), dev(b), flip=bits))
-        assert torch.equal(gx, N.dwconv7x7_nhwc(dev(gy.permute(0, 2, 3, 1).contiguous()), dev(wt), None, flip=1 | bits))
+    # the A/B switches of the launcher (SEA_DWCONV_AB: 2 = plain block order, 4 = one row per lane, 8 = force two rows)
+    import os
+    try:
+        for bits in (2, 4, 6, 8, 10):
+            os.environ["SEA_DWCONV_AB"] = str(bits)
+            assert torch.equal(y, N.dwconv7x7_nhwc(xn, dev(wt), dev(b)))
+            assert torch.equal(gx, N.dwconv7x7_nhwc(dev(gy.permute(0, 2, 3, 1).contiguous()), dev(wt), None, flip=True))
+            assert torch.equal(N.dwconv7x7_nhwc(gyn, dev(wt), None, flip=True, addend=skip), gx + skip)
+    finally:
+        os.environ.pop("SEA_DWCONV_AB", None)
     torch.testing.assert_close(gx.cpu().permute(0, 3, 1, 2).double(), gx_ref, rtol=1e-5, atol=1e-5)
 
 

@@ -213,7 +213,7 @@ def main():
     torch.backends.cudnn.benchmark = True  # MIOpen find mode: pick the fastest conv algorithms
 
     from semseg import _native as N, attacker as A
-    from semseg.models.convnext_upernet import GEMM_TERMS
+    from semseg.models.convnext_upernet import GEMM_TERMS, GEMM_TERMS_BWD
     from semseg.utils.utils import ADE_WTS, VOC_WTS
     N.lib()
     B, C, K, W = args.batch, args.classes, args.steps, args.warmup
@@ -299,15 +299,19 @@ def main():
             "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt * 1e3 / K,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (GEMMs: bf16x3 split MFMA, fp32 accumulate)" if GEMM_TERMS == 3 else "f32", "data": "synthetic",
+            "dtype": (f"f32 (frozen-weight GEMMs on bf16 MFMA by operand splitting: x{GEMM_TERMS} forward, "
+                      f"x{min(GEMM_TERMS, GEMM_TERMS_BWD)} input gradient; fp32 accumulate)") if GEMM_TERMS in (2, 3) else "f32",
+            "data": "synthetic",
             "config": {
                 "workload": f"{'Segmenter-' if args.backbone.startswith('vit_') else 'UperNet-'}{args.backbone} C={C} "
                             f"({'PASCAL-VOC' if C == 21 else 'ADE20K'}-shaped), {B}x512x512 per GPU, APGD L-inf "
                             f"eps={args.eps:g}/255, loss {args.loss}, track ce-avg (BASELINE configs[1] loop body)",
                 "batch_per_gpu": B, "global_batch": world * B, "sharding": f"images x{world}, no in-loop collective",
                 "batch_steps_per_s": world * K / dt, "host_enqueue_ms_per_step": t_enqueue * 1e3 / K,
-                "hip_graph": bool(run.graphs is not None), "gemm": "f32 via bf16x3 split MFMA (sea_gemm_split, 6 products)"
-                if GEMM_TERMS == 3 else ("bf16x2 split MFMA" if GEMM_TERMS == 2 else "hipBLASLt fp32"),
+                "hip_graph": bool(run.graphs is not None),
+                "gemm": (f"sea_gemm_split: forward products bf16x{GEMM_TERMS} split MFMA"
+                         f"{' (= fp32 operands exactly, 6 products)' if GEMM_TERMS == 3 else ''}, input-gradient products "
+                         f"bf16x{min(GEMM_TERMS, GEMM_TERMS_BWD)}, fp32 accumulate") if GEMM_TERMS in (2, 3) else "hipBLASLt fp32",
                 **({"per_rank": per_rank} if per_rank else {}),
             },
             "roofline": roof,

@@ -232,6 +232,11 @@ GEMM_TERMS = int(os.environ.get("SEA_GEMM_TERMS", "3"))
 # Under bf16 autocast (PIR-AT's inner PGD with TRAIN.AMP, BASELINE configs[3]) the decode head's fp32 islands run M8 with
 # TWO terms: 16 significant bits per operand (twice bf16's) at three MFMA products instead of six.
 GEMM_TERMS_AUTOCAST = int(os.environ.get("SEA_GEMM_TERMS_AUTOCAST", "2"))
+# Terms of the INPUT-GRADIENT products.  The attack only uses sign(gradient) (attacker.py:396): 16-bit operands there
+# perturb gradient elements at the 1e-5 level of max|g|, i.e. where rounding already decides the sign (measured with the
+# teacher-forced fixtures, tests/test_teacher_forced_gpu.py), while losses, logits and arg-max maps come from the
+# forward products and keep all three terms.
+GEMM_TERMS_BWD = int(os.environ.get("SEA_GEMM_TERMS_BWD", "2"))
 GEMM_MIN_ROWS = 1024   # below, a 128-row tile grid cannot fill the chip: hipBLASLt's split-K kernels win
 _TERMS_OVERRIDE = [None]
 
@@ -239,6 +244,11 @@ _TERMS_OVERRIDE = [None]
 def _terms():
     """number of bf16 terms M8 uses right now (a Function records it in forward and reuses it in backward)"""
     return GEMM_TERMS if _TERMS_OVERRIDE[0] is None else _TERMS_OVERRIDE[0]
+
+
+def _bwd_terms(fwd_terms):
+    """terms of the input-gradient products of a Function whose forward ran with ``fwd_terms``"""
+    return min(fwd_terms, GEMM_TERMS_BWD) if fwd_terms in (2, 3) and GEMM_TERMS_BWD in (2, 3) else fwd_terms
 
 
 class _gemm_terms:
@@ -294,7 +304,7 @@ class _FrozenLinear(torch.autograd.Function):
         g2 = gy.reshape(-1, gy.shape[-1])
         if not g2.is_contiguous():
             g2 = g2.contiguous()
-        return _frozen_mm(g2, ctx.w, ctx.cache, "lin_bwd", trans=True, terms=ctx.terms).view(ctx.shape), None, None, None
+        return _frozen_mm(g2, ctx.w, ctx.cache, "lin_bwd", trans=True, terms=_bwd_terms(ctx.terms)).view(ctx.shape), None, None, None
 
 
 def _linear_frozen(mod_cache, x, w, b):
@@ -475,7 +485,7 @@ class _PatchConv2x2(torch.autograd.Function):
         B, C, H, W = ctx.shape
         g = gy.permute(0, 2, 3, 1).reshape(-1, gy.shape[1])
         rows = _frozen_mm(g if g.is_contiguous() else g.contiguous(), ctx.wr, ctx.cache, "patch_bwd", trans=True,
-                          terms=ctx.terms).float()
+                          terms=_bwd_terms(ctx.terms)).float()
         if C % 4 == 0 and rows.is_contiguous():
             from .. import _native as N
             gp = N.unpatch2x2(rows, B, H, W)
@@ -581,7 +591,7 @@ class _WinoConv3x3(torch.autograd.Function):
             cache["bwd"] = N.wino_filter(ctx.weight.contiguous(), ctx.m, True)
         gate, gscale = ctx.saved_tensors if ctx.relu else (None, None)
         g = gy if N.cl_pixel_stride(gy) is not None else gy.contiguous(memory_format=_CL)  # slices read in place
-        gx = N.wino_conv3x3_cl(g, cache["bwd"], ctx.m, gate=gate, gate_scale=gscale, gemm_terms=ctx.terms)
+        gx = N.wino_conv3x3_cl(g, cache["bwd"], ctx.m, gate=gate, gate_scale=gscale, gemm_terms=_bwd_terms(ctx.terms))
         return gx, None, None, None, None, None, None
 
 
@@ -639,7 +649,7 @@ class _PointwiseRelu(torch.autograd.Function):
     def backward(ctx, gy):
         (y,) = ctx.saved_tensors
         g = torch.where(y > 0, gy, torch.zeros((), dtype=gy.dtype, device=gy.device))
-        return _frozen_mm(g, ctx.w, ctx.cache, "pw_bwd", trans=True, terms=ctx.terms), None, None, None
+        return _frozen_mm(g, ctx.w, ctx.cache, "pw_bwd", trans=True, terms=_bwd_terms(ctx.terms)), None, None, None
 
 
 class ConvModule(nn.Module):
@@ -870,7 +880,7 @@ class _FpnBottleneck(torch.autograd.Function):
         gz = N.gate_scale(_dense_cl(gy), y, scale)
         grads = [None] * len(shapes)
         if any(ctx.needs_input_grad[5 + i] for i in ctx.hi):
-            gbuf = N.wino_conv3x3_cl(gz, cache["fpn_bwd"], ctx.m, gemm_terms=ctx.terms)
+            gbuf = N.wino_conv3x3_cl(gz, cache["fpn_bwd"], ctx.m, gemm_terms=_bwd_terms(ctx.terms))
             off = 0
             for i in ctx.hi:
                 sl = gbuf[:, off:off + chans[i]]
@@ -882,7 +892,7 @@ class _FpnBottleneck(torch.autograd.Function):
                 h, w = shapes[i][2:]
                 dG = N.tap_gather_backward(gz, (h, w))
                 grads[i] = _frozen_mm(dG.view(B * h * w, -1), cache["fpn_lo"][j], cache, f"fpn_lo_bwd{j}", trans=True,
-                                      terms=ctx.terms).view(B, h, w, chans[i]).permute(0, 3, 1, 2)
+                                      terms=_bwd_terms(ctx.terms)).view(B, h, w, chans[i]).permute(0, 3, 1, 2)
         return (None, None, None, None, None, *grads)
 
 

@@ -15,7 +15,7 @@ struct __attribute__((aligned(16))) LossRecord {
   int n_correct, pad;
 };
 
-__global__ __launch_bounds__(256) void apgd_track_kernel(
+__global__ __launch_bounds__(1024) void apgd_track_kernel(
     const float* __restrict__ loss_sum, const float* __restrict__ track_sum, const int32_t* __restrict__ n_correct,
     const int32_t* __restrict__ n_ignored, int B, int64_t HW, int iter, int n_iter, int check_k, int early_stop,
     int init, int32_t* __restrict__ acc_cnt, float* __restrict__ acc, float* __restrict__ loss_best,
@@ -36,27 +36,50 @@ __global__ __launch_bounds__(256) void apgd_track_kernel(
   // Deferred K2 reduction: sum the per-block records of every image here (fixed order, double), so the
   // loop needs no separate finalize launch.  records[0] is the header {.,., tiles, images}.
   if (records != nullptr) {
-    // one wave per image (4 images in flight): lanes stride over the records, shuffle-reduce in double;
-    // the order is fixed, so the sums are reproducible
+    // Every image's records are split over wpi waves (B = 8 at C = 151: 2048 records per image, 16 waves -> 2 per
+    // image; round 2 summed them with one wave per image, 4 images in flight: 32 us).  Lanes stride over a wave's
+    // contiguous chunk, shuffle-reduce in double, and the wave partials are added in wave order: a fixed order, so the
+    // sums are reproducible run to run.
     const int tiles = records[0].n_correct;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int b = wave; b < B && b < 1024; b += 4) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int wpi = (B >= nw) ? 1 : nw / B;
+    const int groups = nw / wpi;
+    __shared__ double s_pt[16];
+    __shared__ int s_pn[16];
+    for (int b0 = 0; b0 < B && b0 < 1024; b0 += groups) {
+      const int b = b0 + wave / wpi, part = wave % wpi;
       double t = 0.0;
       int n = 0;
-      for (int i = lane; i < tiles; i += 64) {
-        const LossRecord r = records[1 + (int64_t)b * tiles + i];
-        t += (double)r.track;
-        n += r.n_correct;
-      }
+      if (b < B && b < 1024 && wave < groups * wpi) {
+        const int chunk = (tiles + wpi - 1) / wpi;
+        const int i1 = (part + 1) * chunk < tiles ? (part + 1) * chunk : tiles;
+        for (int i = part * chunk + lane; i < i1; i += 64) {
+          const LossRecord r = records[1 + (int64_t)b * tiles + i];
+          t += (double)r.track;
+          n += r.n_correct;
+        }
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        t += __shfl_down(t, o, 64);
-        n += __shfl_down(n, o, 64);
+        for (int o = 32; o > 0; o >>= 1) {
+          t += __shfl_down(t, o, 64);
+          n += __shfl_down(n, o, 64);
+        }
       }
       if (lane == 0) {
-        s_track[b] = (float)t;
-        s_corr[b] = n;
+        s_pt[wave] = t;
+        s_pn[wave] = n;
       }
+      __syncthreads();
+      if (part == 0 && lane == 0 && b < B && b < 1024 && wave < groups * wpi) {
+        double tt = 0.0;
+        int nn = 0;
+        for (int w = 0; w < wpi; ++w) {
+          tt += s_pt[wave + w];
+          nn += s_pn[wave + w];
+        }
+        s_track[b] = (float)tt;
+        s_corr[b] = nn;
+      }
+      __syncthreads();
     }
   }
   __syncthreads();
@@ -207,6 +230,11 @@ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0;
 
 using namespace sea;
 
+// deferred mode (K7 sums K2's records itself): 16 waves; with reduced inputs the kernel is a few per-image scalars
+static inline int track_block(const float* track_sum, const int32_t* n_correct) {
+  return (track_sum && n_correct) ? 256 : 1024;
+}
+
 extern "C" int sea_apgd_track(const float* loss_sum, const float* track_sum, const int32_t* n_correct,
                               const int32_t* n_ignored, int B, int64_t HW, int iter, int n_iter, int check_k,
                               int early_stop, int init, int32_t* acc_cnt, float* acc, float* loss_best,
@@ -218,8 +246,8 @@ extern "C" int sea_apgd_track(const float* loss_sum, const float* track_sum, con
   SEA_CHECK_ARG((track_sum && n_correct) || (loss_workspace && B <= 1024));
   SEA_CHECK_ARG(init || (n_ignored && loss_steps && iter >= 0 && n_iter > 0 && iter < n_iter));
   SEA_CHECK_ARG(check_k >= 0);
-  hipLaunchKernelGGL(apgd_track_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_sum, track_sum, n_correct,
-                     n_ignored, B, HW, iter, n_iter, check_k, early_stop, init, acc_cnt, acc, loss_best,
+  hipLaunchKernelGGL(apgd_track_kernel, dim3(1), dim3(track_block(track_sum, n_correct)), 0, (hipStream_t)stream, loss_sum,
+                     track_sum, n_correct, n_ignored, B, HW, iter, n_iter, check_k, early_stop, init, acc_cnt, acc, loss_best,
                      loss_best_last, reduced_last, step, loss_steps, flags, done,
                      (track_sum && n_correct) ? (const LossRecord*)nullptr : (const LossRecord*)loss_workspace,
                      (int32_t*)nullptr, (const int32_t*)nullptr);
@@ -235,8 +263,8 @@ extern "C" int sea_apgd_track_graph(const float* loss_sum, const float* track_su
   SEA_CHECK_ARG(acc_cnt && acc && loss_best && loss_best_last && reduced_last && step && flags && done && B > 0 &&
                 HW > 0 && iter_dev && check_table && n_ignored && loss_steps && n_iter > 0);
   SEA_CHECK_ARG((track_sum && n_correct) || (loss_workspace && B <= 1024));
-  hipLaunchKernelGGL(apgd_track_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_sum, track_sum, n_correct,
-                     n_ignored, B, HW, 0, n_iter, 0, early_stop, 0, acc_cnt, acc, loss_best, loss_best_last, reduced_last,
+  hipLaunchKernelGGL(apgd_track_kernel, dim3(1), dim3(track_block(track_sum, n_correct)), 0, (hipStream_t)stream, loss_sum,
+                     track_sum, n_correct, n_ignored, B, HW, 0, n_iter, 0, early_stop, 0, acc_cnt, acc, loss_best, loss_best_last, reduced_last,
                      step, loss_steps, flags, done,
                      (track_sum && n_correct) ? (const LossRecord*)nullptr : (const LossRecord*)loss_workspace, iter_dev,
                      check_table);

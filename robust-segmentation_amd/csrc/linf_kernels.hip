@@ -118,17 +118,29 @@ __device__ __forceinline__ float ew2(float p, float q, float eps) {
   }
 }
 
+// two grid-stride positions per trip (four independent 16-byte loads in flight per lane, like K1); the first operand is
+// consumed once (non-temporal), the clean image stays cacheable for the model's first layer
 template <int OP>
-__global__ __launch_bounds__(256) void ew2_v4(const float4* __restrict__ p, const float4* __restrict__ q,
-                                              float eps, float4* __restrict__ out, int64_t n4) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    float4 a = p[i], b = q[i], r;
-    r.x = ew2<OP>(a.x, b.x, eps);
-    r.y = ew2<OP>(a.y, b.y, eps);
-    r.z = ew2<OP>(a.z, b.z, eps);
-    r.w = ew2<OP>(a.w, b.w, eps);
-    out[i] = r;
+__global__ __launch_bounds__(256) void ew2_v4(const f4* __restrict__ p, const f4* __restrict__ q, float eps,
+                                              f4* __restrict__ out, int64_t n4) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += 2 * stride) {
+    const int64_t j = i + stride;
+    const bool hj = j < n4;
+    const int64_t jj = hj ? j : i;
+    const f4 a0 = __builtin_nontemporal_load(p + i), b0 = q[i];
+    const f4 a1 = __builtin_nontemporal_load(p + jj), b1 = q[jj];
+    f4 r0, r1;
+    r0.x = ew2<OP>(a0.x, b0.x, eps);
+    r0.y = ew2<OP>(a0.y, b0.y, eps);
+    r0.z = ew2<OP>(a0.z, b0.z, eps);
+    r0.w = ew2<OP>(a0.w, b0.w, eps);
+    r1.x = ew2<OP>(a1.x, b1.x, eps);
+    r1.y = ew2<OP>(a1.y, b1.y, eps);
+    r1.z = ew2<OP>(a1.z, b1.z, eps);
+    r1.w = ew2<OP>(a1.w, b1.w, eps);
+    out[i] = r0;
+    if (hj) out[j] = r1;
   }
 }
 template <int OP>
@@ -242,8 +254,8 @@ static int launch_ew2(const float* p, const float* q, float eps, float* out, int
   SEA_CHECK_ARG(p && q && out && n > 0);
   hipStream_t s = (hipStream_t)stream;
   if ((n % 4) == 0 && aligned16(p) && aligned16(q) && aligned16(out)) {
-    hipLaunchKernelGGL(ew2_v4<OP>, dim3(grid_for(n / 4, 256)), dim3(256), 0, s, (const float4*)p,
-                       (const float4*)q, eps, (float4*)out, n / 4);
+    hipLaunchKernelGGL(ew2_v4<OP>, dim3(grid_for(n / 4, 256)), dim3(256), 0, s, (const f4*)p, (const f4*)q, eps, (f4*)out,
+                       n / 4);
   } else {
     hipLaunchKernelGGL(ew2_v1<OP>, dim3(grid_for(n, 256)), dim3(256), 0, s, p, q, eps, out, n);
   }

@@ -18,6 +18,7 @@ cfg = yaml.safe_load(open(os.path.join(PKG, "configs", "ade20k_convnext.yaml")))
 cfg["MODEL"]["BACKBONE"] = "ConvNeXt-S_CVST"
 cfg["TRAIN"].update(N_ITERS=int(os.environ.get("PIRAT_N_ITERS", "5")), BATCH_SIZE=8)
 yaml.safe_dump(cfg, open(td + "/cfg.yaml", "w"))
-for flags in ([], ["--bf16"]):
+modes = {"fp32": [[]], "bf16": [["--bf16"]]}.get(os.environ.get("PIRAT_MODE", ""), [[], ["--bf16"]])
+for flags in modes:
     out = td + "/o.json"
     train_rob_seg.main(["--cfg", td + "/cfg.yaml", "--synthetic", "16", "--steps", "6", "--warmup", "2", "--batch_size", "8", "--json", out] + flags)

@@ -341,6 +341,7 @@ class ApgdRun:
         self.k2_events = None  # optional list of (start, end) event pairs, one per step (bench.py)
         self.use_graph = USE_HIP_GRAPH and n_iter >= GRAPH_MIN_ITER   # capture costs ~3 eager iterations
         self.graphs = None
+        self._g_xin = self._g_logits = None
 
     def _loss(self, logits, want_grad):
         ev = None
@@ -453,6 +454,12 @@ class ApgdRun:
         self._loss(self._g_logits, True)
         self.graphs[1].replay()
 
+    def release_graphs(self):
+        """drop the captured graphs and the activations their private pool keeps alive (a run holds several GB of them at
+        B=8, 512x512; an evaluation creates three runs per batch and attack)"""
+        self.graphs = None
+        self._g_xin = self._g_logits = None
+
     def result(self):
         return self.x_best, self.st.acc, self.st.loss_best, self.x_best_adv
 
@@ -523,6 +530,7 @@ def apgd_train(model, x, y, norm, eps, n_iter=10, use_rs=False, loss="ce", verbo
                 done_host.copy_(run.st.done, non_blocking=True)
                 done_evt = torch.cuda.Event()
                 done_evt.record()
+    run.release_graphs()
     if return_pred:
         return run.result() + (run.pred_best,)
     return run.result()

@@ -1,6 +1,5 @@
 #!/bin/bash
-# kernel-level breakdown of the PIR-AT outer step (configs[3]) in steady state: kernels of the last 45 % of the trace
-# (MIOpen's Find candidates and the warm-up steps are in the first part)
+# kernel-level breakdown of the PIR-AT outer step (configs[3]) in steady state: kernels of the last 0.8 s of the trace
 cd ${GRAFT_REPO_ROOT:-.}; export TMPDIR=/tmp
 rm -rf /tmp/pp; PIRAT_MODE=${1:-bf16} timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/pp -- python3 devtools/pirat_bench.py > /tmp/pp.log 2>&1
 f=$(ls /tmp/pp/*/*kernel_trace.csv | head -1)
@@ -8,7 +7,7 @@ python3 - "$f" <<'PY'
 import csv, sys, collections
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(sys.argv[1]))]
 t0, t1 = min(r[0] for r in rows), max(r[1] for r in rows)
-cut = t0 + 0.55 * (t1 - t0)
+cut = t1 - 0.8e9          # the last 0.8 s: ~4 timed outer steps (warm-up and MIOpen's Find are long over)
 agg = collections.defaultdict(lambda: [0, 0])
 for s, e, n in rows:
     if s >= cut:

@@ -327,6 +327,10 @@ int sea_patch2x2(const float* src, float* dst, int B, int H, int W, int C, int i
  * sea_attention_bwd: grad_out (B,T,H*64) contiguous; delta (B,H,T) scratch; dq/dk/dv are written with strides
  *   (gsb, gsh, gst) -- pass slices of one (B,T,3,H,64) gradient tensor to get d(qkv) without a concatenation.
  *   Deterministic (no atomics): S is recomputed in the dq kernel and in the dk/dv kernel.
+ * Arithmetic (round 3, csrc/attention_bf16.hip): by default the products run on v_mfma_f32_32x32x16_bf16 with every fp32
+ *   operand split into bf16 terms, fp32 accumulate: three terms (= the fp32 operands exactly, six products) in the
+ *   forward, two terms in the backward (the attack consumes only the sign of the input gradient).  Environment, read per
+ *   call: SEA_ATTN_TERMS / SEA_ATTN_TERMS_BWD = 3 | 2 | 0 (0 = the fp32 MFMA kernels of csrc/attention.hip).
  */
 int sea_attention_fwd(const float* q, const float* k, const float* v, int64_t sb, int64_t sh, int64_t st, int B, int H,
                       int T, int D, float scale, float* out, float* lse, void* stream);

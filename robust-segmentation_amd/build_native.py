@@ -40,6 +40,7 @@ SOURCES = [
     ("fpn_fused.hip", []),
     ("probe_kernels.hip", []),
     ("attention.hip", []),
+    ("attention_bf16.hip", []),
     ("gemm_split.hip", []),
     ("greedy_host.cpp", ["-ffp-contract=off"]),
     ("api_misc.cpp", []),

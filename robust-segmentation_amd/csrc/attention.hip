@@ -354,12 +354,30 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(AttnPtrs p, int T, int
 
 using namespace sea;
 
+// M7b (csrc/attention_bf16.hip): the same three kernels on the bf16 matrix cores by operand splitting.
+int sea_attention_fwd_bf16(const float* q, const float* k, const float* v, int64_t sb, int64_t sh, int64_t st, int B, int H, int T,
+                           float scale, float* out, float* lse, int terms, hipStream_t stream);
+int sea_attention_bwd_bf16(const float* q, const float* k, const float* v, int64_t sb, int64_t sh, int64_t st, int B, int H, int T,
+                           float scale, const float* grad_out, const float* lse, const float* delta, float* dq, float* dk,
+                           float* dv, int64_t gsb, int64_t gsh, int64_t gst, int terms, hipStream_t stream);
+
+// SEA_ATTN_TERMS (forward) / SEA_ATTN_TERMS_BWD: 3 or 2 = bf16 terms per operand on v_mfma_f32_32x32x16_bf16, 0 = the fp32
+// MFMA kernels of this file.  Defaults: 3 (= the fp32 operands exactly) forward, 2 backward (the attack consumes only the
+// sign of the input gradient).
+static inline int attn_terms(bool backward) {   // looked up per call (two launches per layer): tests switch it in-process
+  const char* e = getenv(backward ? "SEA_ATTN_TERMS_BWD" : "SEA_ATTN_TERMS");
+  const int t = e ? atoi(e) : (backward ? 2 : 3);
+  return (t == 2 || t == 3) ? t : 0;
+}
+
 // q/k/v: element (b,h,t,d) at ptr + b*sb + h*sh + t*st + d (floats), d contiguous, head dim 64, 16-byte aligned rows.
 extern "C" int sea_attention_fwd(const float* q, const float* k, const float* v, int64_t sb, int64_t sh, int64_t st, int B, int H,
                                  int T, int D, float scale, float* out, float* lse, void* stream) {
   SEA_CHECK_ARG(q && k && v && out && lse && B > 0 && H > 0 && T > 0 && D == kD);
   SEA_CHECK_ARG((sb % 4) == 0 && (sh % 4) == 0 && (st % 4) == 0 &&
                 ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)out)) & 15) == 0);
+  if (const int terms = attn_terms(false))
+    return sea_attention_fwd_bf16(q, k, v, sb, sh, st, B, H, T, scale, out, lse, terms, (hipStream_t)stream);
   AttnPtrs p{q, k, v, sb, sh, st};
   dim3 grid((T + 127) / 128, H, B), block(256);
   hipLaunchKernelGGL(attn_fwd_kernel, grid, block, 0, (hipStream_t)stream, p, T, H, scale, out, lse);
@@ -378,6 +396,8 @@ extern "C" int sea_attention_bwd(const float* q, const float* k, const float* v,
   hipStream_t s = (hipStream_t)stream;
   const int64_t rows = (int64_t)B * T * H;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, out, grad_out, T, H, rows, delta);
+  if (const int terms = attn_terms(true))
+    return sea_attention_bwd_bf16(q, k, v, sb, sh, st, B, H, T, scale, grad_out, lse, delta, dq, dk, dv, gsb, gsh, gst, terms, s);
   dim3 grid((T + 127) / 128, H, B), block(256);
   hipLaunchKernelGGL(attn_dq_kernel, grid, block, 0, s, p, T, H, scale, grad_out, lse, delta, dq, gsb, gsh, gst);
   hipLaunchKernelGGL(attn_dkv_kernel, grid, block, 0, s, p, T, H, scale, grad_out, lse, delta, dk, dv, gsb, gsh, gst);

@@ -993,9 +993,22 @@ def test_counts_full_size_ade(N):
 # ------------------------------------------------------------------------------------------------ M7 attention
 @pytest.mark.parametrize("case", [(2, 6, 1025, "ViT-S/16 encoder, 512x512"), (1, 6, 1175, "mask transformer, 1024 patches + 151 classes"),
                                   (3, 2, 64, "one tile"), (1, 1, 33, "ragged"), (2, 3, 130, "two blocks, ragged")])
-def test_fp32_mfma_attention_forward_and_backward(N, case):
-    """softmax(q k^T * scale) v as written in the reference (vit_encoder.py:106-127), explicit fp32 (and an fp64 check)."""
+@pytest.mark.parametrize("terms", [(3, 2), (3, 3), (0, 0)])
+def test_fp32_mfma_attention_forward_and_backward(N, case, terms):
+    """softmax(q k^T * scale) v as written in the reference (vit_encoder.py:106-127), explicit fp32 (and an fp64 check).
+    terms = (forward, backward) bf16 terms per operand of M7b (csrc/attention_bf16.hip); (0, 0) = the fp32 MFMA kernels
+    of M7.  Shipped: (3, 2): forward and log-sum-exp at fp32 level, input gradient with 16-bit operands."""
+    import os
     B, H, T, _ = case
+    os.environ["SEA_ATTN_TERMS"], os.environ["SEA_ATTN_TERMS_BWD"] = str(terms[0]), str(terms[1])
+    try:
+        _attention_case(N, B, H, T, strict_backward=terms[1] != 2)
+    finally:
+        os.environ.pop("SEA_ATTN_TERMS", None)
+        os.environ.pop("SEA_ATTN_TERMS_BWD", None)
+
+
+def _attention_case(N, B, H, T, strict_backward):
     g = torch.Generator().manual_seed(T)
     qkv = torch.randn(B, T, 3, H, 64, generator=g)
     qkv[:, :, 0] *= 1.5                                      # asymmetric operands: a transposed tile would not cancel
@@ -1019,7 +1032,10 @@ def test_fp32_mfma_attention_forward_and_backward(N, case):
     err_g = (dq.cpu().double() - g64).abs().max().item()
     y32, g32 = ref(qkv, torch.float32)                        # the fp32 composition's own error vs fp64 as yardstick
     assert err_y <= max(2e-6, 3 * (y32.double() - y64).abs().max().item()), err_y
-    assert err_g <= max(1e-5, 3 * (g32.double() - g64).abs().max().item()), err_g
+    if strict_backward:
+        assert err_g <= max(1e-5, 3 * (g32.double() - g64).abs().max().item()), err_g
+    else:   # two bf16 terms per operand: 2^-17 relative per product; measured 1.5-1.8e-4 of max|g| ~ 5
+        assert err_g <= 1e-4 * g64.abs().max().item(), (err_g, g64.abs().max().item())
     ref_lse = torch.logsumexp((qkv[:, :, 0].permute(0, 2, 1, 3).double() @ qkv[:, :, 1].permute(0, 2, 3, 1).double()) * scale, -1)
     torch.testing.assert_close(lse.cpu().double(), ref_lse, rtol=1e-6, atol=1e-5)
     # deterministic

@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(AttnPtrsB p, int T
 
 // ---- dK, dV: wave = 32 KEY rows, loop over 64-query tiles: S, dP = dO V^T, dS, dV^T += dO^T P, dK^T += Q^T dS -------------
 template <int TERMS>
-__global__ __launch_bounds__(256, 1) void attn_dkv_bf16_kernel(AttnPtrsB p, int T, int H, float scale, const float* __restrict__ go,
+__global__ __launch_bounds__(256, TERMS == 2 ? 2 : 1) void attn_dkv_bf16_kernel(AttnPtrsB p, int T, int H, float scale, const float* __restrict__ go,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                float* __restrict__ dk, float* __restrict__ dv, int64_t gsb,
                                                                int64_t gsh, int64_t gst) {
@@ -372,10 +372,12 @@ __global__ __launch_bounds__(256, 1) void attn_dkv_bf16_kernel(AttnPtrsB p, int 
   load_row_frag<TERMS>(vb, p.st, k_ld, half, 1.f, vf);
   f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
   const int n_tiles = (T + kTile - 1) / kTile;
-  f32x4 qr[4], gr[4];
-  load_tile_regs(qb, p.st, 0, T, qr);
-  load_tile_regs(gb, gst_o, 0, T, gr);
   for (int j = 0; j < n_tiles; ++j) {
+    // no register prefetch here: four accumulators, two row fragments and the soft-max tiles leave no room for 32
+    // staging registers across the products (they would spill); the second resident block covers the load latency
+    f32x4 qr[4], gr[4];
+    load_tile_regs(qb, p.st, j * kTile, T, qr);
+    load_tile_regs(gb, gst_o, j * kTile, T, gr);
     __syncthreads();
     stage_tile<TERMS, true, true>(q_rm, q_tr, qr);
     stage_tile<TERMS, true, true>(g_rm, g_tr, gr);
@@ -386,13 +388,7 @@ __global__ __launch_bounds__(256, 1) void attn_dkv_bf16_kernel(AttnPtrsB p, int 
       dlt_s[threadIdx.x] = delta[((int64_t)b * H + h) * T + ql];
     }
     __syncthreads();
-    // the next Q tile is requested before the products, the next dO tile after them (its 16 registers would push the
-    // kernel over 256 VGPRs; the other resident block covers that load)
-    if (j + 1 < n_tiles) load_tile_regs(qb, p.st, (j + 1) * kTile, T, qr);
-    if (blockIdx.x * 128 + wave * 32 >= T) {
-      if (j + 1 < n_tiles) load_tile_regs(gb, gst_o, (j + 1) * kTile, T, gr);
-      continue;
-    }
+    if (blockIdx.x * 128 + wave * 32 >= T) continue;
     const int q0 = j * kTile;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
@@ -409,7 +405,6 @@ __global__ __launch_bounds__(256, 1) void attn_dkv_bf16_kernel(AttnPtrsB p, int 
       for (int t = 0; t < 16; ++t) pr[t] = pr[t] * (dp[t] - dlt_s[32 * rb + acc_row(t, half)]) * scale;   // dS (in place)
       tr_times_acc<TERMS>(q_tr, rb, lane, pr, dk0, dk1);                // dK^T += Q^T dS
     }
-    if (j + 1 < n_tiles) load_tile_regs(gb, gst_o, (j + 1) * kTile, T, gr);
   }
   store_rows_t(dk + (int64_t)b * gsb + (int64_t)h * gsh, gst, k_row, k_ok, lane, dk0, dk1, 1.f);
   store_rows_t(dv + (int64_t)b * gsb + (int64_t)h * gsh, gst, k_row, k_ok, lane, dv0, dv1, 1.f);

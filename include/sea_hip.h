@@ -338,6 +338,12 @@ int sea_attention_bwd(const float* q, const float* k, const float* v, int64_t sb
                       int T, int D, float scale, const float* out, const float* grad_out, const float* lse,
                       float* delta, float* dq, float* dk, float* dv, int64_t gsb, int64_t gsh, int64_t gst,
                       void* stream);
+/* sea_attention_bwd with the number of bf16 terms of the backward products given by the caller (3, 2, or 0 = fp32 MFMA):
+ * 3 when the weights are trained through this backward, 2 when only the sign of the input gradient is consumed. */
+int sea_attention_bwd_terms(const float* q, const float* k, const float* v, int64_t sb, int64_t sh, int64_t st, int B, int H,
+                            int T, int D, float scale, const float* out, const float* grad_out, const float* lse,
+                            float* delta, float* dq, float* dk, float* dv, int64_t gsb, int64_t gsh, int64_t gst,
+                            int terms, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * M8  fp32 GEMM with frozen weights on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16) by operand splitting:

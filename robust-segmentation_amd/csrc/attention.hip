@@ -384,10 +384,34 @@ extern "C" int sea_attention_fwd(const float* q, const float* k, const float* v,
   SEA_RETURN_LAST();
 }
 
+static int attention_bwd_impl(const float* q, const float* k, const float* v, int64_t sb, int64_t sh, int64_t st, int B, int H,
+                              int T, int D, float scale, const float* out, const float* grad_out, const float* lse,
+                              float* delta, float* dq, float* dk, float* dv, int64_t gsb, int64_t gsh, int64_t gst,
+                              int bwd_terms, void* stream);
+
 extern "C" int sea_attention_bwd(const float* q, const float* k, const float* v, int64_t sb, int64_t sh, int64_t st, int B, int H,
                                  int T, int D, float scale, const float* out, const float* grad_out, const float* lse,
                                  float* delta, float* dq, float* dk, float* dv, int64_t gsb, int64_t gsh, int64_t gst,
                                  void* stream) {
+  return attention_bwd_impl(q, k, v, sb, sh, st, B, H, T, D, scale, out, grad_out, lse, delta, dq, dk, dv, gsb, gsh, gst,
+                            attn_terms(true), stream);
+}
+
+// same, with the number of bf16 terms of the backward products chosen by the caller (3, 2, or 0 = fp32 MFMA kernels):
+// a caller that ALSO trains the weights through this backward wants 3; an attack that consumes sign(dx) takes 2
+extern "C" int sea_attention_bwd_terms(const float* q, const float* k, const float* v, int64_t sb, int64_t sh, int64_t st, int B,
+                                       int H, int T, int D, float scale, const float* out, const float* grad_out,
+                                       const float* lse, float* delta, float* dq, float* dk, float* dv, int64_t gsb, int64_t gsh,
+                                       int64_t gst, int terms, void* stream) {
+  SEA_CHECK_ARG(terms == 0 || terms == 2 || terms == 3);
+  return attention_bwd_impl(q, k, v, sb, sh, st, B, H, T, D, scale, out, grad_out, lse, delta, dq, dk, dv, gsb, gsh, gst, terms,
+                            stream);
+}
+
+static int attention_bwd_impl(const float* q, const float* k, const float* v, int64_t sb, int64_t sh, int64_t st, int B, int H,
+                              int T, int D, float scale, const float* out, const float* grad_out, const float* lse,
+                              float* delta, float* dq, float* dk, float* dv, int64_t gsb, int64_t gsh, int64_t gst,
+                              int bwd_terms, void* stream) {
   SEA_CHECK_ARG(q && k && v && out && grad_out && lse && delta && dq && dk && dv && B > 0 && H > 0 && T > 0 && D == kD);
   SEA_CHECK_ARG((sb % 4) == 0 && (sh % 4) == 0 && (st % 4) == 0 && (gsb % 4) == 0 && (gsh % 4) == 0 && (gst % 4) == 0);
   SEA_CHECK_ARG(((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)out) | ((uintptr_t)grad_out) |
@@ -396,7 +420,7 @@ extern "C" int sea_attention_bwd(const float* q, const float* k, const float* v,
   hipStream_t s = (hipStream_t)stream;
   const int64_t rows = (int64_t)B * T * H;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, out, grad_out, T, H, rows, delta);
-  if (const int terms = attn_terms(true))
+  if (const int terms = bwd_terms)
     return sea_attention_bwd_bf16(q, k, v, sb, sh, st, B, H, T, scale, grad_out, lse, delta, dq, dk, dv, gsb, gsh, gst, terms, s);
   dim3 grid((T + 127) / 128, H, B), block(256);
   hipLaunchKernelGGL(attn_dq_kernel, grid, block, 0, s, p, T, H, scale, grad_out, lse, delta, dq, gsb, gsh, gst);

@@ -70,6 +70,8 @@ _SIGS = {
     "sea_attention_fwd": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "sea_attention_bwd": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                _i64, _i64, _i64, _vp]),
+    "sea_attention_bwd_terms": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                     _i64, _i64, _i64, _i, _vp]),
     "sea_gemm_split_packed_bytes": (_i64, [_i, _i, _i]),
     "sea_gemm_split_pack": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp]),
     "sea_gemm_split": (_i, [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _vp]),
@@ -629,8 +631,9 @@ def attention_qkv(qkv, scale: float):
     return out, lse
 
 
-def attention_qkv_backward(qkv, out, lse, grad_out, scale: float):
-    """gradient w.r.t. the packed qkv tensor"""
+def attention_qkv_backward(qkv, out, lse, grad_out, scale: float, terms=None):
+    """gradient w.r.t. the packed qkv tensor.  ``terms``: bf16 terms of the backward products (3, 2, 0 = fp32 MFMA);
+    None = the library default (2, or SEA_ATTN_TERMS_BWD)."""
     _dev(qkv, out, lse, grad_out)
     B, T, _, H, D = qkv.shape
     grad_out = _f32c(grad_out.contiguous())
@@ -638,9 +641,12 @@ def attention_qkv_backward(qkv, out, lse, grad_out, scale: float):
     delta = torch.empty_like(lse)
     p, g = qkv.data_ptr(), dqkv.data_ptr()
     sb, sh, st = T * 3 * H * D, D, 3 * H * D
-    _check(lib().sea_attention_bwd(p, p + 4 * H * D, p + 8 * H * D, sb, sh, st, B, H, T, D, float(scale), _p(_f32c(out)),
-                                   _p(grad_out), _p(_f32c(lse)), _p(delta), g, g + 4 * H * D, g + 8 * H * D, sb, sh, st,
-                                   _stream()), "sea_attention_bwd")
+    args = (p, p + 4 * H * D, p + 8 * H * D, sb, sh, st, B, H, T, D, float(scale), _p(_f32c(out)), _p(grad_out),
+            _p(_f32c(lse)), _p(delta), g, g + 4 * H * D, g + 8 * H * D, sb, sh, st)
+    if terms is None:
+        _check(lib().sea_attention_bwd(*args, _stream()), "sea_attention_bwd")
+    else:
+        _check(lib().sea_attention_bwd_terms(*args, int(terms), _stream()), "sea_attention_bwd_terms")
     return dqkv
 
 

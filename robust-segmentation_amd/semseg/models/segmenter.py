@@ -49,11 +49,11 @@ class _AttentionHip(torch.autograd.Function):
 
     @staticmethod
     @_fp32_fwd
-    def forward(ctx, qkv, scale):
+    def forward(ctx, qkv, scale, train=False):
         from .. import _native as N
         out, lse = N.attention_qkv(qkv, scale)
         ctx.save_for_backward(qkv, out, lse)
-        ctx.scale = scale
+        ctx.scale, ctx.train = scale, train
         return out
 
     @staticmethod
@@ -61,7 +61,9 @@ class _AttentionHip(torch.autograd.Function):
     def backward(ctx, g):
         from .. import _native as N
         qkv, out, lse = ctx.saved_tensors
-        return N.attention_qkv_backward(qkv, out, lse, g, ctx.scale), None
+        # weights trained through this backward: three bf16 terms per operand (fp32 level); an attack only consumes the
+        # sign of the input gradient: the library default (two terms)
+        return N.attention_qkv_backward(qkv, out, lse, g, ctx.scale, terms=3 if ctx.train else None), None, None
 
 
 class Attention(nn.Module):
@@ -82,7 +84,7 @@ class Attention(nn.Module):
         p = self.attn_drop.p if self.training else 0.0
         if (USE_HIP_ATTENTION and p == 0.0 and qkv.is_cuda and qkv.dtype == torch.float32 and D // self.heads == 64
                 and qkv.is_contiguous()):
-            y = _AttentionHip.apply(qkv.view(B, T, 3, self.heads, 64), self.scale)
+            y = _AttentionHip.apply(qkv.view(B, T, 3, self.heads, 64), self.scale, self.qkv.weight.requires_grad)
             return self.proj_drop(_linear_frozen(gc[1], y, self.proj.weight, self.proj.bias))
         q, k, v = qkv.reshape(B, T, 3, self.heads, D // self.heads).permute(2, 0, 3, 1, 4)
         y = F.scaled_dot_product_attention(q, k, v, dropout_p=p, scale=self.scale)

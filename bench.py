@@ -299,8 +299,10 @@ def main():
             "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt * 1e3 / K,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": (f"f32 (frozen-weight GEMMs on bf16 MFMA by operand splitting: x{GEMM_TERMS} forward, "
-                      f"x{min(GEMM_TERMS, GEMM_TERMS_BWD)} input gradient; fp32 accumulate)") if GEMM_TERMS in (2, 3) else "f32",
+            "dtype": ("f32 (frozen-weight GEMMs on the 16-bit matrix cores by operand splitting: "
+                      + ("fp16x2 = 22 significant bits" if GEMM_TERMS == 22 else f"bf16x{GEMM_TERMS}") + " forward, bf16x"
+                      + str(GEMM_TERMS_BWD if GEMM_TERMS == 22 else min(GEMM_TERMS, GEMM_TERMS_BWD))
+                      + " input gradient; fp32 accumulate)") if GEMM_TERMS in (2, 3, 22) else "f32",
             "data": "synthetic",
             "config": {
                 "workload": f"{'Segmenter-' if args.backbone.startswith('vit_') else 'UperNet-'}{args.backbone} C={C} "
@@ -309,9 +311,10 @@ def main():
                 "batch_per_gpu": B, "global_batch": world * B, "sharding": f"images x{world}, no in-loop collective",
                 "batch_steps_per_s": world * K / dt, "host_enqueue_ms_per_step": t_enqueue * 1e3 / K,
                 "hip_graph": bool(run.graphs is not None),
-                "gemm": (f"sea_gemm_split: forward products bf16x{GEMM_TERMS} split MFMA"
-                         f"{' (= fp32 operands exactly, 6 products)' if GEMM_TERMS == 3 else ''}, input-gradient products "
-                         f"bf16x{min(GEMM_TERMS, GEMM_TERMS_BWD)}, fp32 accumulate") if GEMM_TERMS in (2, 3) else "hipBLASLt fp32",
+                "gemm": ("sea_gemm_split: forward products " + ("fp16x2 split MFMA (22 significant bits per operand, 3 products)"
+                         if GEMM_TERMS == 22 else f"bf16x{GEMM_TERMS} split MFMA") + ", input-gradient products bf16x"
+                         + str(GEMM_TERMS_BWD if GEMM_TERMS == 22 else min(GEMM_TERMS, GEMM_TERMS_BWD)) + ", fp32 accumulate")
+                if GEMM_TERMS in (2, 3, 22) else "hipBLASLt fp32",
                 **({"per_rank": per_rank} if per_rank else {}),
             },
             "roofline": roof,

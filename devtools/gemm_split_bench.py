@@ -42,7 +42,7 @@ def timed(fn, reps=10):
 
 
 def main():
-    tot = {"lib": 0.0, 3: 0.0, 2: 0.0}
+    tot = {"lib": 0.0, 3: 0.0, 22: 0.0, 2: 0.0}
     for name, G, M, K, Nn in SHAPES:
         A = torch.randn(G, M, K, device="cuda")
         W = torch.randn(G, Nn, K, device="cuda") / K ** 0.5
@@ -51,7 +51,7 @@ def main():
         t_lib = timed(lambda: torch.bmm(A, Wt) if G > 1 else torch.mm(A[0], Wt[0]))
         row = f"{name:36s} G={G:2d} M={M:6d} K={K:4d} N={Nn:4d}  hipBLASLt fp32 {t_lib * 1e3:8.1f} us {flop / t_lib / 1e9:6.1f} TF/s"
         ref = (A[0, :512].double() @ W[0].double().t())
-        for terms in (3, 2):
+        for terms in (3, 22, 2):
             Wp = N.gemm_split_pack(W, terms=terms)
             out = torch.empty(G, M, Nn, device="cuda")
             t = timed(lambda: N.gemm_split(A, Wp, out=out))
@@ -62,7 +62,7 @@ def main():
         e_lib = ((torch.bmm(A, Wt) if G > 1 else torch.mm(A[0], Wt[0])).reshape(G, M, Nn)[0, :512].double() - ref).abs().max().item() / ref.abs().max().item()
         print(row + f" | lib err {e_lib:.1e}", flush=True)
         del A, W, Wt, out
-    print(f"sum over shapes: hipBLASLt {tot['lib']:.2f} ms   3 terms {tot[3]:.2f} ms   2 terms {tot[2]:.2f} ms")
+    print(f"sum over shapes: hipBLASLt {tot['lib']:.2f} ms   bf16x3 {tot[3]:.2f} ms   fp16x2 {tot[22]:.2f} ms   bf16x2 {tot[2]:.2f} ms")
 
 
 if __name__ == "__main__":

@@ -356,8 +356,17 @@ int sea_attention_bwd_terms(const float* q, const float* k, const float* v, int6
  *   batch strides in elements (A, C) / bytes (packed W).  K % 32 == 0, lda % 4 == 0, A 16-byte aligned.
  * sea_gemm_split_pack: W (N x K row-major, or K x N with trans = 1; row stride ldw) -> the packed, pre-split image the
  *   kernel reads ([K/32][terms][ceil128(N)][32] bf16, sea_gemm_split_packed_bytes bytes).  Done once per weight.
+ * terms = 22 selects fp16 x 2 operands instead (hi = fp16(x*s), mid = fp16(x*s - hi): 22 significant bits, three
+ *   products on v_mfma_f32_32x32x16_f16): fp16 has 5 exponent bits, so the weights are packed with a power-of-two scale per
+ *   output row and the activations are scaled by a power of two derived from max|A|, which the caller obtains on the device
+ *   with sea_absmax_bits (one 4-byte word, no host round trip) and hands to sea_gemm_split_f16; the epilogue undoes both
+ *   scales exactly.  Elements more than 2^28 below the tensor's maximum flush to zero.
  */
 int64_t sea_gemm_split_packed_bytes(int N, int K, int terms);
+int sea_absmax_bits(const float* A, int64_t lda, int M, int K, int batch, int64_t strideA, uint32_t* out_bits, void* stream);
+int sea_gemm_split_f16(const float* A, int64_t lda, const void* Wp, float* C, int64_t ldc, const float* bias, int relu, int M,
+                       int N, int K, int batch, int64_t strideA, int64_t strideW_bytes, int64_t strideC,
+                       const uint32_t* amax_bits, void* stream);
 int sea_gemm_split_pack(const float* W, int64_t ldw, int trans, int N, int K, int terms, void* out, void* stream);
 int sea_gemm_split(const float* A, int64_t lda, const void* Wp, float* C, int64_t ldc, const float* bias, int relu, int M,
                    int N, int K, int terms, int batch, int64_t strideA, int64_t strideW_bytes, int64_t strideC,

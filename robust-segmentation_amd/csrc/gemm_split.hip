@@ -38,6 +38,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int GS_BM = 128, GS_BN = 128, GS_BK = 32;
 constexpr int GS_IMG = GS_BM * GS_BK * 2;  // bytes of one term image (128 rows x 64 B)
@@ -63,6 +65,31 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2 (&out)[TERMS]) {
   }
 }
 
+// fp16 x 2: hi = fp16(a * s), mid = fp16(a * s - hi): 2 x 11 = 22 significant bits per operand, three products
+// (hi*hi', hi*mid', mid*hi'; the dropped mid*mid' is 2^-22 relative).  fp16 has 5 exponent bits, so every operand tensor
+// is scaled by a power of two s that puts its largest magnitude just below 2^14 (products < 2^28, fp32 accumulate); the
+// epilogue multiplies by the exact inverse.  Elements more than 2^28 below the tensor's maximum flush to zero.
+__device__ __forceinline__ uint32_t pack_f16(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+}
+__device__ __forceinline__ void split4_f16(const f32x4 v, float s, u32x2 (&out)[2]) {
+  const float a0 = v[0] * s, a1 = v[1] * s, a2 = v[2] * s, a3 = v[3] * s;
+  const uint32_t h0 = pack_f16(a0, a1), h1 = pack_f16(a2, a3);
+  const f32x2 f0 = __builtin_convertvector(__builtin_bit_cast(f16x2, h0), f32x2);
+  const f32x2 f1 = __builtin_convertvector(__builtin_bit_cast(f16x2, h1), f32x2);
+  out[0] = u32x2{h0, h1};
+  out[1] = u32x2{pack_f16(a0 - f0[0], a1 - f0[1]), pack_f16(a2 - f1[0], a3 - f1[1])};
+}
+// power-of-two scale for a tensor whose largest |value| has the float bits `amax_bits`: amax * scale < 2^14
+__device__ __host__ __forceinline__ void pow2_scale(uint32_t amax_bits, float& scale, float& inv) {
+  int E = (int)((amax_bits >> 23) & 0xffu);   // amax in [2^(E-127), 2^(E-126))
+  E = E < 14 ? 14 : (E > 253 ? 253 : E);
+  const uint32_t sb = (uint32_t)(267 - E) << 23, ib = (uint32_t)(E - 13) << 23;
+  scale = __builtin_bit_cast(float, sb);        // 2^(140 - E)
+  inv = __builtin_bit_cast(float, ib);          // 2^(E - 140)
+}
+
 // 16-byte chunk swizzle inside a 64-byte row.  ds_read_b128 is served in four 16-lane groups {0-3,12-15,20-27},
 // {4-11,16-19,28-31}, +32; a group must touch 16 distinct 16-byte slots of the 256-byte bank row:
 //   32x32x16 fragments (lane -> row l & 31, chunk 2s + (l >> 5)):   chunk ^ ((row >> 2) & 3)
@@ -82,9 +109,11 @@ struct GemmSplitArgs {
   int M, N, K, Npad;
   int mblocks, nblocks, total, per_xcd;
   int relu;
+  const uint32_t* amax_bits;   // fp16 x 2 only: float bits of max |A| (device memory)
+  const float* w_inv;          // fp16 x 2 only: per-column inverse weight scale
 };
 
-template <int TERMS, bool S16>
+template <int TERMS, bool S16, bool F16 = false>
 __global__ __launch_bounds__(256, 3) void gemm_split_kernel(const GemmSplitArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * TERMS * GS_IMG];
   char* As = smem;
@@ -94,6 +123,8 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(const GemmSplitArgs 
   // blocks that share an A tile run on one XCD at the same time and meet in its L2
   const int M = p.M, N = p.N, K = p.K, Npad = p.Npad;   // (locals: the lambdas below must not take the address of p)
   const int64_t lda = p.lda, ldc = p.ldc;
+  float a_scale = 1.f, a_inv = 1.f;
+  if constexpr (F16) pow2_scale(*p.amax_bits, a_scale, a_inv);
   const int logical = (int)(blockIdx.x & 7) * p.per_xcd + (int)(blockIdx.x >> 3);
   if ((int)(blockIdx.x >> 3) >= p.per_xcd || logical >= p.total) return;
   const int nb = logical % p.nblocks;
@@ -101,6 +132,7 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(const GemmSplitArgs 
   const int mb = t2 % p.mblocks;
   const int g = t2 / p.mblocks;
   const int m0 = mb * GS_BM, n0 = nb * GS_BN;
+  const float* const w_inv = F16 ? (const float*)((const char*)p.w_inv + (int64_t)g * p.strideW) : nullptr;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -143,7 +175,10 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(const GemmSplitArgs 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       u32x2 s[TERMS];
-      split4<TERMS>(pa[i], s);
+      if constexpr (F16)
+        split4_f16(pa[i], a_scale, s);
+      else
+        split4<TERMS>(pa[i], s);
       const int row = arow + 32 * i;
 #pragma unroll
       for (int t = 0; t < TERMS; ++t) *(u32x2*)(As + t * GS_IMG + row * 64 + swz<S16>(row, q >> 1) + (q & 1) * 8) = s[t];
@@ -194,14 +229,20 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(const GemmSplitArgs 
           for (int ni = 0; ni < 2; ++ni) {
             f32x16 c = acc[mi][ni];
             // smallest products first
-            if constexpr (TERMS == 3) {
-              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][2], b[ni][0], c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][2], c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][1], c, 0, 0, 0);
+            if constexpr (F16) {
+              c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[mi][1]), __builtin_bit_cast(f16x8, b[ni][0]), c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[mi][0]), __builtin_bit_cast(f16x8, b[ni][1]), c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[mi][0]), __builtin_bit_cast(f16x8, b[ni][0]), c, 0, 0, 0);
+            } else {
+              if constexpr (TERMS == 3) {
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][2], b[ni][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][1], c, 0, 0, 0);
+              }
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][0], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][1], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][0], c, 0, 0, 0);
             }
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][0], c, 0, 0, 0);
             acc[mi][ni] = c;
           }
       }
@@ -213,6 +254,7 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(const GemmSplitArgs 
       const int col = n0 + wn * 64 + ni * 32 + r;
       if (col >= N) continue;
       const float bv = bias ? bias[col] : 0.f;
+      const float un = F16 ? a_inv * w_inv[col] : 1.f;   // exact: both scales are powers of two
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
         const int rbase = m0 + wm * 64 + mi * 32 + 4 * h;
@@ -220,7 +262,7 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(const GemmSplitArgs 
         for (int e = 0; e < 16; ++e) {
           const int row = rbase + (e & 3) + 8 * (e >> 2);
           if (row < M) {
-            float v = acc[mi][ni][e] + bv;
+            float v = (F16 ? acc[mi][ni][e] * un : acc[mi][ni][e]) + bv;
             if (relu) v = v > 0.f ? v : 0.f;
             Cg[(int64_t)row * ldc + col] = v;
           }
@@ -321,24 +363,123 @@ __global__ void gemm_split_pack_kernel(const float* __restrict__ W, int64_t ldw,
   }
 }
 
+// max |x| of a (batch of) row-strided matrix as float bits (non-negative floats order like their bit patterns):
+// order-independent, so the atomic makes it deterministic.  `out` must be zeroed before.
+__global__ __launch_bounds__(256) void absmax_bits_kernel(const float* __restrict__ A, int64_t lda, int M, int K4,
+                                                          int64_t strideA, int batch, uint32_t* __restrict__ out) {
+  uint32_t m = 0;
+  auto take = [&](const f32x4 v) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t b = __float_as_uint(v[e]) & 0x7fffffffu;
+      m = b > m ? b : m;
+    }
+  };
+  if (lda == (int64_t)4 * K4 && (batch == 1 || strideA == (int64_t)M * lda)) {
+    // dense: one flat stream, two 16-byte loads in flight per lane (the GEMM that follows finds the data in L2 / MALL)
+    const int64_t total = (int64_t)batch * M * K4, stride = (int64_t)gridDim.x * blockDim.x;
+    const f32x4* p = reinterpret_cast<const f32x4*>(A);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += 2 * stride) {
+      const int64_t j = i + stride;
+      const f32x4 v0 = p[i], v1 = p[j < total ? j : i];
+      take(v0);
+      take(v1);
+    }
+  } else {
+    // row-strided: a block walks whole rows
+    const int64_t rows = (int64_t)batch * M;
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+      const int64_t g = r / M;
+      const float* row = A + g * strideA + (r - g * M) * lda;
+      for (int k4 = threadIdx.x; k4 < K4; k4 += blockDim.x) take(*reinterpret_cast<const f32x4*>(row + 4 * k4));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t other = (uint32_t)__shfl_xor((int)m, o, 64);
+    m = other > m ? other : m;
+  }
+  // ONE atomic per block: thousands of same-address atomics serialise in L2 (8192 of them cost ~100 us)
+  __shared__ uint32_t wave_max[4];
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t b = wave_max[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) b = wave_max[w] > b ? wave_max[w] : b;
+    if (b) atomicMax(out, b);
+  }
+}
+
+// per-row max |w| bits of W (N x K, or K x N with trans)
+__global__ void rowmax_bits_kernel(const float* __restrict__ W, int64_t ldw, int trans, int N, int K, uint32_t* __restrict__ out) {
+  const int n = blockIdx.x;
+  uint32_t m = 0;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    const uint32_t b = __float_as_uint(trans ? W[(int64_t)k * ldw + n] : W[(int64_t)n * ldw + k]) & 0x7fffffffu;
+    m = b > m ? b : m;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t other = (uint32_t)__shfl_xor((int)m, o, 64);
+    m = other > m ? other : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out + n, m);
+}
+
+// W -> [K/32][2][Npad][32] fp16 (hi, mid) of w * 2^s_n, + the inverse scales 2^-s_n (Npad floats) behind the images
+__global__ void gemm_split_pack_f16_kernel(const float* __restrict__ W, int64_t ldw, int trans, int N, int K, int Npad,
+                                           const uint32_t* __restrict__ rowmax, uint16_t* __restrict__ out,
+                                           float* __restrict__ w_inv) {
+  const int64_t total = (int64_t)(K / 32) * Npad * 32;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int kk = (int)(i & 31);
+    const int64_t t = i >> 5;
+    const int n = (int)(t % Npad);
+    const int kb = (int)(t / Npad);
+    const int k = kb * 32 + kk;
+    float sc = 1.f, inv = 1.f;
+    if (n < N) pow2_scale(rowmax[n], sc, inv);
+    if (kb == 0 && kk == 0) w_inv[n] = n < N ? inv : 0.f;
+    const float w = n < N ? (trans ? W[(int64_t)k * ldw + n] : W[(int64_t)n * ldw + k]) * sc : 0.f;
+    const uint32_t hi = pack_f16(w, 0.f) & 0xffffu;
+    const float hf = (float)__builtin_bit_cast(f16x2, hi)[0];
+    const uint32_t mid = pack_f16(w - hf, 0.f) & 0xffffu;
+    out[(((int64_t)kb * 2 + 0) * Npad + n) * 32 + kk] = (uint16_t)hi;
+    out[(((int64_t)kb * 2 + 1) * Npad + n) * 32 + kk] = (uint16_t)mid;
+  }
+}
+
 }  // namespace sea
 
 using namespace sea;
 
 static inline int gs_npad(int N) { return (N + GS_BN - 1) / GS_BN * GS_BN; }
 
+// terms: 3 / 2 = bf16 terms per operand; 22 = fp16 x 2 (22 significant bits, per-tensor power-of-two scaling)
 extern "C" int64_t sea_gemm_split_packed_bytes(int N, int K, int terms) {
-  if (N <= 0 || K <= 0 || K % GS_BK || (terms != 2 && terms != 3)) return -1;
+  if (N <= 0 || K <= 0 || K % GS_BK || (terms != 2 && terms != 3 && terms != 22)) return -1;
+  if (terms == 22) return (int64_t)(K / GS_BK) * 2 * gs_npad(N) * GS_BK * 2 + (int64_t)gs_npad(N) * 8;   // + inverse scales, row maxima
   return (int64_t)(K / GS_BK) * terms * gs_npad(N) * GS_BK * 2;
 }
 
 extern "C" int sea_gemm_split_pack(const float* W, int64_t ldw, int trans, int N, int K, int terms, void* out,
                                    void* stream) {
-  SEA_CHECK_ARG(W && out && N > 0 && K > 0 && (K % GS_BK) == 0 && (terms == 2 || terms == 3));
+  SEA_CHECK_ARG(W && out && N > 0 && K > 0 && (K % GS_BK) == 0 && (terms == 2 || terms == 3 || terms == 22));
   SEA_CHECK_ARG(ldw >= (trans ? N : K));
   const int Npad = gs_npad(N);
   const int64_t total = (int64_t)(K / 32) * Npad * 32;
   const int grid = grid_for(total, 256);
+  if (terms == 22) {
+    char* base = (char*)out;
+    float* w_inv = (float*)(base + (int64_t)(K / GS_BK) * 2 * Npad * GS_BK * 2);
+    uint32_t* rowmax = (uint32_t*)(w_inv + Npad);
+    hipMemsetAsync(rowmax, 0, (size_t)Npad * 4, (hipStream_t)stream);
+    hipLaunchKernelGGL(rowmax_bits_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, W, ldw, trans, N, K, rowmax);
+    hipLaunchKernelGGL(gemm_split_pack_f16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, ldw, trans, N, K, Npad,
+                       rowmax, (uint16_t*)out, w_inv);
+    SEA_RETURN_LAST();
+  }
   if (terms == 3)
     hipLaunchKernelGGL(gemm_split_pack_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, ldw, trans, N, K, Npad,
                        (uint16_t*)out);
@@ -348,10 +489,40 @@ extern "C" int sea_gemm_split_pack(const float* W, int64_t ldw, int trans, int N
   SEA_RETURN_LAST();
 }
 
+static int gemm_split_impl(const float* A, int64_t lda, const void* Wp, float* C, int64_t ldc, const float* bias, int relu, int M,
+                           int N, int K, int terms, int batch, int64_t strideA, int64_t strideW_bytes, int64_t strideC,
+                           const uint32_t* amax_bits, void* stream);
+
 extern "C" int sea_gemm_split(const float* A, int64_t lda, const void* Wp, float* C, int64_t ldc, const float* bias,
                               int relu, int M, int N, int K, int terms, int batch, int64_t strideA, int64_t strideW_bytes,
                               int64_t strideC, void* stream) {
-  SEA_CHECK_ARG(A && Wp && C && M > 0 && N > 0 && K > 0 && (K % GS_BK) == 0 && batch > 0 && (terms == 2 || terms == 3));
+  SEA_CHECK_ARG(terms == 2 || terms == 3);
+  return gemm_split_impl(A, lda, Wp, C, ldc, bias, relu, M, N, K, terms, batch, strideA, strideW_bytes, strideC, nullptr, stream);
+}
+
+// fp16 x 2 operands (weights packed with terms = 22).  amax_bits: device word that sea_absmax_bits filled for THIS A.
+extern "C" int sea_gemm_split_f16(const float* A, int64_t lda, const void* Wp, float* C, int64_t ldc, const float* bias,
+                                  int relu, int M, int N, int K, int batch, int64_t strideA, int64_t strideW_bytes,
+                                  int64_t strideC, const uint32_t* amax_bits, void* stream) {
+  SEA_CHECK_ARG(amax_bits != nullptr);
+  return gemm_split_impl(A, lda, Wp, C, ldc, bias, relu, M, N, K, 22, batch, strideA, strideW_bytes, strideC, amax_bits, stream);
+}
+
+extern "C" int sea_absmax_bits(const float* A, int64_t lda, int M, int K, int batch, int64_t strideA, uint32_t* out_bits,
+                               void* stream) {
+  SEA_CHECK_ARG(A && out_bits && M > 0 && K > 0 && (K % 4) == 0 && (lda % 4) == 0 && batch > 0 && (((uintptr_t)A) & 15) == 0);
+  hipMemsetAsync(out_bits, 0, 4, (hipStream_t)stream);
+  const int64_t total = (int64_t)batch * M * (K / 4);
+  int grid = grid_for(total, 512);   // two float4 per lane and trip
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(absmax_bits_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, A, lda, M, K / 4, strideA, batch, out_bits);
+  SEA_RETURN_LAST();
+}
+
+static int gemm_split_impl(const float* A, int64_t lda, const void* Wp, float* C, int64_t ldc, const float* bias, int relu, int M,
+                           int N, int K, int terms, int batch, int64_t strideA, int64_t strideW_bytes, int64_t strideC,
+                           const uint32_t* amax_bits, void* stream) {
+  SEA_CHECK_ARG(A && Wp && C && M > 0 && N > 0 && K > 0 && (K % GS_BK) == 0 && batch > 0);
   SEA_CHECK_ARG(lda >= K && ldc >= N && (lda % 4) == 0 && (int64_t)M * lda < (1ll << 30));  // 32-bit lane offsets into A
   SEA_CHECK_ARG(((((uintptr_t)A) | ((uintptr_t)Wp)) & 15) == 0 && (((uintptr_t)C) & 3) == 0 && (strideA % 4) == 0 &&
                 (strideW_bytes % 16) == 0);
@@ -376,6 +547,8 @@ extern "C" int sea_gemm_split(const float* A, int64_t lda, const void* Wp, float
   p.total = (int)total;
   p.per_xcd = (p.total + 7) / 8;
   p.relu = relu;
+  p.amax_bits = amax_bits;
+  p.w_inv = terms == 22 ? (const float*)((const char*)Wp + (int64_t)(K / GS_BK) * 2 * gs_npad(N) * GS_BK * 2) : nullptr;
   const dim3 grid(p.per_xcd * 8), block(256);
   // MFMA shape: v_mfma_f32_32x32x16_bf16 fragments (default); SEA_GEMM_SHAPE=16 selects v_mfma_f32_16x16x32_bf16
   // (measured within +-3 % of each other on the shapes of devtools/gemm_split_bench.py)
@@ -383,6 +556,10 @@ extern "C" int sea_gemm_split(const float* A, int64_t lda, const void* Wp, float
     const char* e = getenv("SEA_GEMM_SHAPE");
     return (e && e[0] == '1') ? 1 : 0;
   }();
+  if (terms == 22) {
+    hipLaunchKernelGGL((gemm_split_kernel<2, false, true>), grid, block, 0, (hipStream_t)stream, p);
+    SEA_RETURN_LAST();
+  }
   if (terms == 3) {
     if (shape16)
       hipLaunchKernelGGL((gemm_split_kernel<3, true>), grid, block, 0, (hipStream_t)stream, p);

@@ -72,6 +72,8 @@ _SIGS = {
                                _i64, _i64, _i64, _vp]),
     "sea_attention_bwd_terms": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _i64, _i64, _i64, _i, _vp]),
+    "sea_absmax_bits": (_i, [_vp, _i64, _i, _i, _i, _i64, _vp, _vp]),
+    "sea_gemm_split_f16": (_i, [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _i, _i64, _i64, _i64, _vp, _vp]),
     "sea_gemm_split_packed_bytes": (_i64, [_i, _i, _i]),
     "sea_gemm_split_pack": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp]),
     "sea_gemm_split": (_i, [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _vp]),
@@ -543,7 +545,7 @@ def wino_conv3x3_cl(x, U, m: int, bias=None, scale=None, relu: bool = False, gat
         _check(L.sea_wino_input_transform(_p(t), xps, _p(gate), _p(gate_scale), V.data_ptr() + 4 * off, Cin, B, t.shape[1],
                                           H, W, m, _stream()), "sea_wino_input_transform")
         off += t.shape[1]
-    if gemm_terms in (2, 3) and Cin % 32 == 0 and T >= 256:
+    if gemm_terms in (2, 3, 22) and Cin % 32 == 0 and T >= 256:
         # M8: the (A*A) Winograd-domain products on the bf16 matrix cores (operands split into bf16 terms, fp32 accumulate)
         packed = U.__dict__.setdefault("_sea_packed", {})   # U is the cached, frozen filter image: packed once per term count
         Up = packed.get(gemm_terms)
@@ -690,7 +692,7 @@ def gemm_split_pack(W, trans: bool = False, terms: int = 3) -> PackedWeight:
     L = lib()
     nbytes = L.sea_gemm_split_packed_bytes(N, K, terms)
     if nbytes < 0:
-        raise SeaNativeError(f"gemm_split_pack: unsupported shape N={N} K={K} terms={terms} (K % 32 == 0, terms 2 or 3)")
+        raise SeaNativeError(f"gemm_split_pack: unsupported shape N={N} K={K} terms={terms} (K % 32 == 0, terms 2, 3 or 22)")
     out = torch.empty(G, nbytes, dtype=torch.uint8, device=W.device)
     for g in range(G):
         _check(L.sea_gemm_split_pack(_p(Wb[g]), Wb.stride(1), int(trans), N, K, terms, _p(out[g]), _stream()),
@@ -715,7 +717,14 @@ def gemm_split(A, Wp: PackedWeight, bias=None, relu: bool = False, out=None):
         raise SeaNativeError("gemm_split: output must be float32 (.., M, N) with a contiguous last dim")
     if bias is not None and (bias.dtype != torch.float32 or bias.numel() != Wp.N or not bias.is_contiguous()):
         raise SeaNativeError("gemm_split: bias must be contiguous float32 of N entries")
+    sA, sC = (A3.stride(0) if G > 1 else 0), (O3.stride(0) if G > 1 else 0)
+    if Wp.terms == 22:
+        # fp16 x 2: the activation scale comes from max|A|, computed on the device (no host round trip)
+        amax = torch.empty(1, dtype=torch.int32, device=A.device)
+        _check(lib().sea_absmax_bits(_p(A3), A3.stride(1), M, K, G, sA, _p(amax), _stream()), "sea_absmax_bits")
+        _check(lib().sea_gemm_split_f16(_p(A3), A3.stride(1), _p(Wp.data), _p(O3), O3.stride(1), _p(bias), int(relu), M, Wp.N,
+                                        K, G, sA, Wp.stride, sC, _p(amax), _stream()), "sea_gemm_split_f16")
+        return out
     _check(lib().sea_gemm_split(_p(A3), A3.stride(1), _p(Wp.data), _p(O3), O3.stride(1), _p(bias), int(relu), M, Wp.N, K,
-                                Wp.terms, G, A3.stride(0) if G > 1 else 0, Wp.stride, O3.stride(0) if G > 1 else 0,
-                                _stream()), "sea_gemm_split")
+                                Wp.terms, G, sA, Wp.stride, sC, _stream()), "sea_gemm_split")
     return out

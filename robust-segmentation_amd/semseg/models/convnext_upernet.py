@@ -224,11 +224,14 @@ def _tkey(*ts):
 
 
 # M8 (csrc/gemm_split.hip): the frozen-weight GEMMs of the attacked model on the bf16 matrix cores by operand splitting.
-#   3: every fp32 operand as three bf16 terms, six MFMA products -> fp32-level accuracy (default)
+#   3: every fp32 operand as three bf16 terms, six MFMA products -> fp32-level accuracy
 #   2: two terms, three products (16 significant bits per operand; 64x finer than the TF32 convolutions the reference's
 #      own GPU runs use by default)
+#  22: fp16 x 2 (hi + mid = 22 significant bits, three products; operands scaled per tensor / per weight row by powers
+#      of two because fp16 has 5 exponent bits; the activation's scale comes from a device-side max|A| pass): measured
+#      error vs float64 <= the fp32 GEMM's own, at half the matrix-core work of 3 -> the default of the FORWARD products
 #   0: hipBLASLt fp32 (torch.mm / bmm / addmm), as in rounds 1-2
-GEMM_TERMS = int(os.environ.get("SEA_GEMM_TERMS", "3"))
+GEMM_TERMS = int(os.environ.get("SEA_GEMM_TERMS", "22"))
 # Under bf16 autocast (PIR-AT's inner PGD with TRAIN.AMP, BASELINE configs[3]) the decode head's fp32 islands run M8 with
 # TWO terms: 16 significant bits per operand (twice bf16's) at three MFMA products instead of six.
 GEMM_TERMS_AUTOCAST = int(os.environ.get("SEA_GEMM_TERMS_AUTOCAST", "2"))
@@ -248,6 +251,8 @@ def _terms():
 
 def _bwd_terms(fwd_terms):
     """terms of the input-gradient products of a Function whose forward ran with ``fwd_terms``"""
+    if fwd_terms == 22:                      # fp16 x 2 forward: the input gradient keeps the range-safe bf16 terms
+        return GEMM_TERMS_BWD if GEMM_TERMS_BWD in (2, 3) else 3
     return min(fwd_terms, GEMM_TERMS_BWD) if fwd_terms in (2, 3) and GEMM_TERMS_BWD in (2, 3) else fwd_terms
 
 
@@ -264,7 +269,7 @@ class _gemm_terms:
 
 
 def _split_ok(x2d, K, terms=None):
-    return ((_terms() if terms is None else terms) in (2, 3) and x2d.is_cuda and x2d.dtype == torch.float32 and x2d.dim() == 2 and K % 32 == 0
+    return ((_terms() if terms is None else terms) in (2, 3, 22) and x2d.is_cuda and x2d.dtype == torch.float32 and x2d.dim() == 2 and K % 32 == 0
             and x2d.stride(1) == 1 and x2d.stride(0) % 4 == 0 and x2d.data_ptr() % 16 == 0
             and x2d.shape[0] >= GEMM_MIN_ROWS and not torch.is_autocast_enabled())
 
@@ -309,7 +314,7 @@ class _FrozenLinear(torch.autograd.Function):
 
 def _linear_frozen(mod_cache, x, w, b):
     """F.linear through M8 when the weights are frozen and the shape qualifies; plain F.linear otherwise."""
-    if (_terms() in (2, 3) and x.is_cuda and x.dtype == torch.float32 and not w.requires_grad
+    if (_terms() in (2, 3, 22) and x.is_cuda and x.dtype == torch.float32 and not w.requires_grad
             and (b is None or not b.requires_grad) and w.shape[1] % 32 == 0 and not torch.is_autocast_enabled()
             and x.is_contiguous() and x.numel() // x.shape[-1] >= GEMM_MIN_ROWS):
         return _FrozenLinear.apply(x, w, b, mod_cache)

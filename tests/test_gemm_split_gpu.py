@@ -48,7 +48,9 @@ def test_accuracy_matches_fp32_gemm(N, M, K, Nn):
     e_lib = ((A @ W.t()).double() - ref).abs().max().item() / scale
     e3 = (N.gemm_split(A, N.gemm_split_pack(W, terms=3)).double() - ref).abs().max().item() / scale
     e2 = (N.gemm_split(A, N.gemm_split_pack(W, terms=2)).double() - ref).abs().max().item() / scale
-    print(f"M={M} K={K} N={Nn}: max err / max|C|  hipBLASLt fp32 {e_lib:.2e}   3 terms {e3:.2e}   2 terms {e2:.2e}")
+    e22 = (N.gemm_split(A, N.gemm_split_pack(W, terms=22)).double() - ref).abs().max().item() / scale
+    print(f"M={M} K={K} N={Nn}: max err / max|C|  hipBLASLt fp32 {e_lib:.2e}   bf16x3 {e3:.2e}   fp16x2 {e22:.2e}   bf16x2 {e2:.2e}")
+    assert e22 <= max(6.0 * e_lib, 2e-6), (e22, e_lib)        # 22 significant bits per operand
     assert e3 <= max(4.0 * e_lib, 1e-6) and e3 <= 3e-6, (e3, e_lib)   # fp32-level (measured: 0.8-2.4x hipBLASLt's fp32 error)
     assert e2 <= 2e-5, e2                                      # 16 significant bits per operand
 
@@ -83,3 +85,25 @@ def test_rejects_bad_arguments(N):
     Wp = N.gemm_split_pack(torch.randn(16, 64, device="cuda"))
     with pytest.raises(N.SeaNativeError):
         N.gemm_split(A, Wp)                                            # K mismatch
+
+
+def test_fp16x2_handles_extreme_scales(N):
+    """fp16 has 5 exponent bits: the per-tensor / per-row power-of-two scaling must keep tiny and huge operands exact
+    enough (relative to the result's scale) and must never overflow"""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for a_scale, w_scale in ((1e-6, 1.0), (3e4, 1.0), (1.0, 1e-5), (2e3, 5e2), (1e-20, 1e10)):
+        A = torch.randn(512, 128, generator=g, device="cuda") * a_scale
+        W = torch.randn(192, 128, generator=g, device="cuda") * w_scale
+        W[5] *= 1e-4                                          # a weight row far below the others: its own scale
+        ref = _ref(A, W)
+        out = N.gemm_split(A, N.gemm_split_pack(W, terms=22))
+        assert torch.isfinite(out).all()
+        col = ref.abs().amax(0).clamp_min(1e-300)
+        assert ((out.double() - ref).abs().amax(0) / col).max().item() <= 5e-6, (a_scale, w_scale)
+    # batch of packed weights (the Winograd-domain products): one activation scale for the batch, one weight scale per row and g
+    A = torch.randn(4, 300, 64, generator=g, device="cuda")
+    W = torch.randn(4, 200, 64, generator=g, device="cuda") * torch.tensor([1.0, 1e-3, 50.0, 1e2], device="cuda").view(4, 1, 1)
+    ref = _ref(A, W)
+    out = N.gemm_split(A, N.gemm_split_pack(W, terms=22))
+    for i in range(4):
+        assert (out[i].double() - ref[i]).abs().max().item() <= 3e-6 * ref[i].abs().max().item()

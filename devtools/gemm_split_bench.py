@@ -12,6 +12,7 @@ import torch  # noqa: E402
 from semseg import _native as N  # noqa: E402
 
 SHAPES = [  # (name, G, M, K, N)
+    ("winograd F(4,3) 2048->512 @128^2", 36, 8192, 2048, 512),
     ("winograd F(4,3) 512->512 @128^2", 36, 8192, 512, 512),
     ("winograd F(4,3) 512->512 @64^2", 36, 2048, 512, 512),
     ("winograd F(4,3) 2816->512 @16^2", 36, 128, 2816, 512),
@@ -51,10 +52,13 @@ def main():
         t_lib = timed(lambda: torch.bmm(A, Wt) if G > 1 else torch.mm(A[0], Wt[0]))
         row = f"{name:36s} G={G:2d} M={M:6d} K={K:4d} N={Nn:4d}  hipBLASLt fp32 {t_lib * 1e3:8.1f} us {flop / t_lib / 1e9:6.1f} TF/s"
         ref = (A[0, :512].double() @ W[0].double().t())
+        floor = 4.0 * G * (M * K + M * Nn) / 5.5e12 * 1e3       # ms: A read once + C written once at 5.5 TB/s
+        row += f" | HBM floor {floor * 1e3:7.1f} us"
+        amax = A.abs().max().reshape(1).view(torch.int32)
         for terms in (3, 22, 2):
             Wp = N.gemm_split_pack(W, terms=terms)
             out = torch.empty(G, M, Nn, device="cuda")
-            t = timed(lambda: N.gemm_split(A, Wp, out=out))
+            t = timed(lambda: N.gemm_split(A, Wp, out=out, amax=amax if terms == 22 else None))
             err = (out[0, :512].double() - ref).abs().max().item() / ref.abs().max().item()
             tot[terms] += t
             row += f" | {terms} terms {t * 1e3:8.1f} us {flop / t / 1e9:6.1f} TF/s err {err:.1e}"

@@ -3,9 +3,9 @@
 #   bash devtools/gemm_split_pmc.sh G M K N terms
 cd ${GRAFT_REPO_ROOT:-.}; export TMPDIR=/tmp
 OUT=gpurun_out/gemm_pmc; rm -rf /tmp/gp; mkdir -p $OUT /tmp/gp
-echo "== $* SEA_GEMM_WIDE=${SEA_GEMM_WIDE:-1}" >> $OUT/summary.txt
+echo "== $*" >> $OUT/summary.txt
 i=0
-for grp in "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY"; do
+for grp in "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM"; do
   i=$((i+1))
   timeout 120 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/gp/$i -- python3 devtools/gemm_split_case.py "$@" > /tmp/gp/log$i.txt 2>&1 || tail -3 /tmp/gp/log$i.txt
   f=$(ls /tmp/gp/$i/*/*counter_collection.csv 2>/dev/null | head -1)

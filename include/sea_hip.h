@@ -277,6 +277,11 @@ int64_t sea_wino_tiles(int B, int H, int W, int m);
 int sea_wino_input_transform(const float* x, int64_t x_pixel_stride, const float* gate, const float* scale,
                              float* V, int64_t v_tile_stride, int B, int C, int H, int W, int m, void* stream);
 int sea_wino_filter_transform(const float* w, float* U, int Cout, int Cin, int m, int flip, void* stream);
+/* sea_wino_input_transform that also max-accumulates, per tile t, the float bits of max|V[.][t][.]| into amax_out[t]
+ * (sea_wino_tiles pre-zeroed words): the per-row fp16 x 2 scales of the Winograd-domain GEMMs (sea_gemm_split_f16 with
+ * amax_rows = 1), each depending on its own tile only.  T < 2^31. */
+int sea_wino_input_transform_amax(const float* x, int64_t x_pixel_stride, const float* gate, const float* scale, float* V,
+                                  int64_t v_tile_stride, int B, int C, int H, int W, int m, uint32_t* amax_out, void* stream);
 int sea_wino_output_transform(const float* M, const float* addend, const float* scale, const float* bias,
                               int relu, float* y, int B, int C, int H, int W, int m, void* stream);
 
@@ -363,11 +368,46 @@ int sea_attention_bwd_terms(const float* q, const float* k, const float* v, int6
  *   scales exactly.  Elements more than 2^28 below the tensor's maximum flush to zero.
  */
 int64_t sea_gemm_split_packed_bytes(int N, int K, int terms);
-int sea_absmax_bits(const float* A, int64_t lda, int M, int K, int batch, int64_t strideA, uint32_t* out_bits, void* stream);
+int sea_absmax_bits(const float* A, int64_t lda, int M, int K, int batch, int64_t strideA, int rows_per_word,
+                    uint32_t* out_bits, void* stream);
 int sea_gemm_split_f16(const float* A, int64_t lda, const void* Wp, float* C, int64_t ldc, const float* bias, int relu, int M,
                        int N, int K, int batch, int64_t strideA, int64_t strideW_bytes, int64_t strideC,
-                       const uint32_t* amax_bits, void* stream);
+                       const uint32_t* amax_bits, int amax_rows, uint32_t* out_amax, void* stream);
+/* The activation scale is a power of two PER ROW of A, taken from amax_bits[row / amax_rows] (amax_rows = 0: one word for
+ * the whole tensor): a word is the float bits of any upper bound of max|A| over its rows (all batch entries).  With one
+ * word per image (amax_rows = rows of an image) or per row, an image's result does not depend on the images it shares a
+ * batch with -- a per-tensor scale moves the sub-normal cut-off of the low fp16 term with the batch maximum, which changes
+ * last bits and was measured to break the sharded evaluation's bitwise 1-rank == 2-rank property.
+ * sea_absmax_bits(rows_per_word) computes the words exactly (rows_per_word = 0: one word); producers can supply them for
+ * free: sea_wino_input_transform_amax (one word per tile), analytic bounds (LayerNorm output: sqrt(C) max|w| + max|b|; a
+ * GEMM's output: bound(input) * max_n ||W_n||_1 + max|bias|), or the out_amax word (whole-tensor max|C|) of the GEMM whose
+ * output feeds a non-expanding element-wise function.  A loose bound costs nothing up to a factor ~2^10 (fp16 is floating
+ * point: only the sub-normal cut-off of the low term moves; error <= looseness * 2^-40 of the bound). */
 int sea_gemm_split_pack(const float* W, int64_t ldw, int trans, int N, int K, int terms, void* out, void* stream);
+/* sea_gemm_splitk_reduce: second pass of a split-K product.  A GEMM whose 128 x 128 tile grid cannot fill the chip (few
+ * rows, long K: the point-wise layers of the last ConvNeXt stages, the FPN taps' input gradient) is launched as a BATCH of
+ * `splits` GEMMs over K slices (batch strides of sea_gemm_split: A + s K/splits, packed slices of W) into a dense
+ * (splits, M, N) workspace; this kernel adds the slices in the fixed order 0, 1, .. (bitwise reproducible), then bias,
+ * ReLU and the optional max|C| word.  N % 4 == 0, ldc % 4 == 0, 16-byte aligned pointers. */
+int sea_gemm_splitk_reduce(const float* partial, int splits, int M, int N, const float* bias, int relu, float* C, int64_t ldc,
+                           uint32_t* out_amax, void* stream);
+/* sea_gemm_split_fused: the same GEMM (terms 2 / 3 / 22; amax_bits / out_amax as above, 22 only) with the element-wise
+ * neighbours of the MLP of a ConvNeXt / ViT block (convnext_orig.py:38-58, vit_encoder.py:41-60) in its epilogue:
+ *   v = A W^T + bias + addend;  relu;  v *= GELU'(gelu_grad_of);  C = v;  gelu_out = GELU(v)     (exact erf GELU)
+ * addend: the residual of the block (forward of the second projection); gelu_out: forward of the first projection (C keeps
+ * the pre-activation the backward needs); gelu_grad_of: backward of the second projection (the gradient of the first
+ * projection's output, without a separate GELU-backward pass).  gelu_out / gelu_grad_of have C's layout (ldc, strideC).
+ * epi may be NULL (= sea_gemm_split / sea_gemm_split_f16). */
+typedef struct SeaGemmEpilogue {
+  const float* addend;
+  int64_t ld_addend, stride_addend;
+  float* gelu_out;
+  const float* gelu_grad_of;
+} SeaGemmEpilogue;
+int sea_gemm_split_fused(const float* A, int64_t lda, const void* Wp, float* C, int64_t ldc, const float* bias, int relu, int M,
+                         int N, int K, int terms, int batch, int64_t strideA, int64_t strideW_bytes, int64_t strideC,
+                         const uint32_t* amax_bits, int amax_rows, uint32_t* out_amax, const SeaGemmEpilogue* epi,
+                         void* stream);
 int sea_gemm_split(const float* A, int64_t lda, const void* Wp, float* C, int64_t ldc, const float* bias, int relu, int M,
                    int N, int K, int terms, int batch, int64_t strideA, int64_t strideW_bytes, int64_t strideC,
                    void* stream);

@@ -109,11 +109,27 @@ struct GemmSplitArgs {
   int M, N, K, Npad;
   int mblocks, nblocks, total, per_xcd;
   int relu;
-  const uint32_t* amax_bits;   // fp16 x 2 only: float bits of max |A| (device memory)
+  const uint32_t* amax_bits;   // fp16 x 2 only: float bits of max |A| (device memory): one word, or one per amax_rows rows
+  int amax_rows;
   const float* w_inv;          // fp16 x 2 only: per-column inverse weight scale
+  uint32_t* out_amax;          // optional: atomic max of the float bits of |C| (pre-zeroed word), for a consumer GEMM
+  // fused epilogue extras (sea_gemm_split_fused): all optional
+  const float* addend;         // + addend[g][m][n] before the activation (row stride ld_add, batch stride stride_add)
+  int64_t ld_add, stride_add;
+  float* gelu_out;             // layout of C: receives GELU(C); C keeps the pre-activation
+  const float* gelu_grad_of;   // layout of C: the result is multiplied by GELU'(this)
 };
 
-template <int TERMS, bool S16, bool F16 = false>
+// exact (erf) GELU and its derivative, the formulas of ATen's GeluCUDAKernelImpl / GeluBackwardCUDAKernelImpl
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+  const float pdf = __expf(-0.5f * x * x) * 0.39894228040143267794f;   // M_2_SQRTPI * M_SQRT1_2 * 0.5
+  return cdf + x * pdf;
+}
+
+// EPI: the fused epilogue extras (addend / gelu_out / gelu_grad_of) are compiled in
+template <int TERMS, bool S16, bool F16 = false, bool EPI = false>
 __global__ __launch_bounds__(256, 3) void gemm_split_kernel(const GemmSplitArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * TERMS * GS_IMG];
   char* As = smem;
@@ -123,8 +139,6 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(const GemmSplitArgs 
   // blocks that share an A tile run on one XCD at the same time and meet in its L2
   const int M = p.M, N = p.N, K = p.K, Npad = p.Npad;   // (locals: the lambdas below must not take the address of p)
   const int64_t lda = p.lda, ldc = p.ldc;
-  float a_scale = 1.f, a_inv = 1.f;
-  if constexpr (F16) pow2_scale(*p.amax_bits, a_scale, a_inv);
   const int logical = (int)(blockIdx.x & 7) * p.per_xcd + (int)(blockIdx.x >> 3);
   if ((int)(blockIdx.x >> 3) >= p.per_xcd || logical >= p.total) return;
   const int nb = logical % p.nblocks;
@@ -148,6 +162,27 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(const GemmSplitArgs 
   const float* const bias = p.bias;
   const int64_t strideC = p.strideC;
   const int relu = p.relu;
+  const float* const addg = (EPI && p.addend) ? p.addend + (int64_t)g * p.stride_add : nullptr;
+  const int64_t ld_add = p.ld_add;
+  float* const gelu_out = (EPI && p.gelu_out) ? p.gelu_out + (int64_t)g * p.strideC : nullptr;
+  const float* const gelu_src = (EPI && p.gelu_grad_of) ? p.gelu_grad_of + (int64_t)g * p.strideC : nullptr;
+  // fp16 x 2: one power-of-two scale per ROW of the tile, from the word that covers the row (the whole tensor, an image,
+  // a Winograd tile ..): rows scaled by their own group's maximum make an image's result independent of its batch partners
+  __shared__ float row_sc[F16 ? GS_BM : 1], row_inv[F16 ? GS_BM : 1];
+  float a_sc[4] = {1.f, 1.f, 1.f, 1.f};
+  if constexpr (F16) {
+    if (tid < GS_BM) {
+      int row = m0 + tid;
+      row = row < M ? row : M - 1;
+      float sc, inv;
+      pow2_scale(p.amax_bits[p.amax_rows > 0 ? row / p.amax_rows : 0], sc, inv);
+      row_sc[tid] = sc;
+      row_inv[tid] = inv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_sc[i] = row_sc[arow + 32 * i];
+  }
   uint32_t aoff[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -176,7 +211,7 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(const GemmSplitArgs 
     for (int i = 0; i < 4; ++i) {
       u32x2 s[TERMS];
       if constexpr (F16)
-        split4_f16(pa[i], a_scale, s);
+        split4_f16(pa[i], a_sc[i], s);
       else
         split4<TERMS>(pa[i], s);
       const int row = arow + 32 * i;
@@ -249,12 +284,13 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(const GemmSplitArgs 
       __syncthreads();
     }
     // ---- epilogue: lane = column, 16 registers = rows (reg & 3) + 8 (reg >> 2) + 4 h of the 32 x 32 tile
+    uint32_t omax = 0;
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       const int col = n0 + wn * 64 + ni * 32 + r;
       if (col >= N) continue;
       const float bv = bias ? bias[col] : 0.f;
-      const float un = F16 ? a_inv * w_inv[col] : 1.f;   // exact: both scales are powers of two
+      const float wi = F16 ? w_inv[col] : 1.f;
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
         const int rbase = m0 + wm * 64 + mi * 32 + 4 * h;
@@ -262,12 +298,26 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(const GemmSplitArgs 
         for (int e = 0; e < 16; ++e) {
           const int row = rbase + (e & 3) + 8 * (e >> 2);
           if (row < M) {
-            float v = (F16 ? acc[mi][ni][e] * un : acc[mi][ni][e]) + bv;
+            // (exact: both scales are powers of two)
+            float v = (F16 ? acc[mi][ni][e] * (row_inv[row - m0] * wi) : acc[mi][ni][e]) + bv;
+            if (EPI && addg) v += addg[(int64_t)row * ld_add + col];
             if (relu) v = v > 0.f ? v : 0.f;
+            if (EPI && gelu_src) v *= gelu_grad_f(gelu_src[(int64_t)row * ldc + col]);
             Cg[(int64_t)row * ldc + col] = v;
+            if (EPI && gelu_out) gelu_out[(int64_t)row * ldc + col] = gelu_f(v);
+            const uint32_t vb = __float_as_uint(v) & 0x7fffffffu;
+            omax = vb > omax ? vb : omax;
           }
         }
       }
+    }
+    if (p.out_amax != nullptr) {   // wave-uniform branch; one conditional atomic per wave, skipped once the word is large enough
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)omax, o, 64);
+        omax = other > omax ? other : omax;
+      }
+      if (lane == 0 && omax > *(volatile uint32_t*)p.out_amax) atomicMax(p.out_amax, omax);
     }
   } else {
     // ---- 16x16x32 fragments: one 32-deep MFMA step per staged tile, 4 x 4 output tiles of 16 x 16 per wave.  The chip
@@ -331,8 +381,11 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(const GemmSplitArgs 
           const int row = m0 + wm * 64 + mi * 16 + 4 * c16 + e;
           if (row < M) {
             float v = acc[mi][ni][e] + bv;
+            if (EPI && addg) v += addg[(int64_t)row * ld_add + col];
             if (relu) v = v > 0.f ? v : 0.f;
+            if (EPI && gelu_src) v *= gelu_grad_f(gelu_src[(int64_t)row * ldc + col]);
             Cg[(int64_t)row * ldc + col] = v;
+            if (EPI && gelu_out) gelu_out[(int64_t)row * ldc + col] = gelu_f(v);
           }
         }
       }
@@ -450,6 +503,92 @@ __global__ void gemm_split_pack_f16_kernel(const float* __restrict__ W, int64_t 
   }
 }
 
+// out[j] = float bits of max |A[g][r][:]| over all g and the rows r of group j (rows j rpw .. (j + 1) rpw - 1)
+__global__ __launch_bounds__(256) void absmax_groups_kernel(const float* __restrict__ A, int64_t lda, int M, int K4,
+                                                            int64_t strideA, int batch, int rpw, uint32_t* __restrict__ out) {
+  const int j = blockIdx.y;
+  const int r0 = j * rpw, r1 = (r0 + rpw < M) ? r0 + rpw : M;
+  uint32_t m = 0;
+  const int64_t n = (int64_t)(r1 - r0) * K4;
+  for (int g = 0; g < batch; ++g) {
+    const float* base = A + (int64_t)g * strideA + (int64_t)r0 * lda;
+    if (lda == (int64_t)4 * K4) {
+      const f32x4* p = reinterpret_cast<const f32x4*>(base);
+      for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 v = p[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t b = __float_as_uint(v[e]) & 0x7fffffffu;
+          m = b > m ? b : m;
+        }
+      }
+    } else {
+      for (int r = blockIdx.x; r < r1 - r0; r += gridDim.x)
+        for (int k4 = threadIdx.x; k4 < K4; k4 += blockDim.x) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(base + (int64_t)r * lda + 4 * k4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t b = __float_as_uint(v[e]) & 0x7fffffffu;
+            m = b > m ? b : m;
+          }
+        }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t other = (uint32_t)__shfl_xor((int)m, o, 64);
+    m = other > m ? other : m;
+  }
+  __shared__ uint32_t wave_max[4];
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t b = wave_max[0];
+    for (int w = 1; w < 4; ++w) b = wave_max[w] > b ? wave_max[w] : b;
+    if (b > *(volatile uint32_t*)(out + j)) atomicMax(out + j, b);
+  }
+}
+
+// zero-fill of a few words as a KERNEL: inside a captured HIP graph a hipMemsetAsync node was observed to run out of order
+// with the neighbouring kernel nodes (the max|A| word was cleared after sea_absmax_bits had accumulated into it: replays
+// differed from the eager loop on 1 of 6 runs with 8 such nodes per graph, on 6 of 6 with 48)
+__global__ void zero_words_kernel(uint32_t* __restrict__ p, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0u;
+}
+
+// C[m][n] = act(sum_s partial[s][m][n] + bias[n]) in the fixed order s = 0, 1, ..: the second pass of a split-K product
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const f32x4* __restrict__ part, int S, int64_t per_split4, int M,
+                                                            int N4, const f32x4* __restrict__ bias, int relu,
+                                                            float* __restrict__ C, int64_t ldc, uint32_t* __restrict__ out_amax) {
+  const int64_t total = (int64_t)M * N4;
+  uint32_t omax = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / N4;
+    const int c4 = (int)(i - row * N4);
+    f32x4 v = part[i];
+    for (int sidx = 1; sidx < S; ++sidx) v += part[sidx * per_split4 + i];
+    if (bias) v += bias[c4];
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+    }
+    *(f32x4*)(C + row * ldc + 4 * c4) = v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t vb = __float_as_uint(v[e]) & 0x7fffffffu;
+      omax = vb > omax ? vb : omax;
+    }
+  }
+  if (out_amax != nullptr) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t other = (uint32_t)__shfl_xor((int)omax, o, 64);
+      omax = other > omax ? other : omax;
+    }
+    if ((threadIdx.x & 63) == 0 && omax > *(volatile uint32_t*)out_amax) atomicMax(out_amax, omax);
+  }
+}
+
 }  // namespace sea
 
 using namespace sea;
@@ -474,7 +613,7 @@ extern "C" int sea_gemm_split_pack(const float* W, int64_t ldw, int trans, int N
     char* base = (char*)out;
     float* w_inv = (float*)(base + (int64_t)(K / GS_BK) * 2 * Npad * GS_BK * 2);
     uint32_t* rowmax = (uint32_t*)(w_inv + Npad);
-    hipMemsetAsync(rowmax, 0, (size_t)Npad * 4, (hipStream_t)stream);
+    hipLaunchKernelGGL(zero_words_kernel, dim3((Npad + 255) / 256), dim3(256), 0, (hipStream_t)stream, rowmax, Npad);
     hipLaunchKernelGGL(rowmax_bits_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, W, ldw, trans, N, K, rowmax);
     hipLaunchKernelGGL(gemm_split_pack_f16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, ldw, trans, N, K, Npad,
                        rowmax, (uint16_t*)out, w_inv);
@@ -491,27 +630,72 @@ extern "C" int sea_gemm_split_pack(const float* W, int64_t ldw, int trans, int N
 
 static int gemm_split_impl(const float* A, int64_t lda, const void* Wp, float* C, int64_t ldc, const float* bias, int relu, int M,
                            int N, int K, int terms, int batch, int64_t strideA, int64_t strideW_bytes, int64_t strideC,
-                           const uint32_t* amax_bits, void* stream);
+                           const uint32_t* amax_bits, int amax_rows, uint32_t* out_amax, void* stream,
+                           const SeaGemmEpilogue* epi = nullptr);
 
 extern "C" int sea_gemm_split(const float* A, int64_t lda, const void* Wp, float* C, int64_t ldc, const float* bias,
                               int relu, int M, int N, int K, int terms, int batch, int64_t strideA, int64_t strideW_bytes,
                               int64_t strideC, void* stream) {
   SEA_CHECK_ARG(terms == 2 || terms == 3);
-  return gemm_split_impl(A, lda, Wp, C, ldc, bias, relu, M, N, K, terms, batch, strideA, strideW_bytes, strideC, nullptr, stream);
+  return gemm_split_impl(A, lda, Wp, C, ldc, bias, relu, M, N, K, terms, batch, strideA, strideW_bytes, strideC, nullptr, 0,
+                         nullptr, stream);
 }
 
 // fp16 x 2 operands (weights packed with terms = 22).  amax_bits: device word that sea_absmax_bits filled for THIS A.
+// out_amax (optional, pre-zeroed word): receives the float bits of max |C| -- the scale of a consumer GEMM whose input is an
+// element-wise function of C that does not grow it (GELU, ReLU), without another pass over C.
 extern "C" int sea_gemm_split_f16(const float* A, int64_t lda, const void* Wp, float* C, int64_t ldc, const float* bias,
                                   int relu, int M, int N, int K, int batch, int64_t strideA, int64_t strideW_bytes,
-                                  int64_t strideC, const uint32_t* amax_bits, void* stream) {
-  SEA_CHECK_ARG(amax_bits != nullptr);
-  return gemm_split_impl(A, lda, Wp, C, ldc, bias, relu, M, N, K, 22, batch, strideA, strideW_bytes, strideC, amax_bits, stream);
+                                  int64_t strideC, const uint32_t* amax_bits, int amax_rows, uint32_t* out_amax,
+                                  void* stream) {
+  SEA_CHECK_ARG(amax_bits != nullptr && amax_rows >= 0);
+  return gemm_split_impl(A, lda, Wp, C, ldc, bias, relu, M, N, K, 22, batch, strideA, strideW_bytes, strideC, amax_bits,
+                         amax_rows, out_amax, stream);
 }
 
-extern "C" int sea_absmax_bits(const float* A, int64_t lda, int M, int K, int batch, int64_t strideA, uint32_t* out_bits,
-                               void* stream) {
+// act(A W^T + bias + addend) with optional second output GELU(.) / factor GELU'(.): see include/sea_hip.h
+extern "C" int sea_gemm_split_fused(const float* A, int64_t lda, const void* Wp, float* C, int64_t ldc, const float* bias,
+                                    int relu, int M, int N, int K, int terms, int batch, int64_t strideA,
+                                    int64_t strideW_bytes, int64_t strideC, const uint32_t* amax_bits, int amax_rows,
+                                    uint32_t* out_amax, const SeaGemmEpilogue* epi, void* stream) {
+  SEA_CHECK_ARG(terms == 2 || terms == 3 || (terms == 22 && amax_bits != nullptr && amax_rows >= 0));
+  SEA_CHECK_ARG(terms == 22 || out_amax == nullptr);
+  if (epi) {
+    SEA_CHECK_ARG(!epi->addend || epi->ld_addend >= N);
+    SEA_CHECK_ARG(!(epi->gelu_out && epi->gelu_grad_of) && !(relu && (epi->gelu_out || epi->gelu_grad_of)));
+  }
+  return gemm_split_impl(A, lda, Wp, C, ldc, bias, relu, M, N, K, terms, batch, strideA, strideW_bytes, strideC,
+                         terms == 22 ? amax_bits : nullptr, amax_rows, out_amax, stream, epi);
+}
+
+// split-K second pass: C (M x N, row stride ldc) = act(sum over `splits` partial products (each M x N, dense) + bias)
+extern "C" int sea_gemm_splitk_reduce(const float* partial, int splits, int M, int N, const float* bias, int relu, float* C,
+                                      int64_t ldc, uint32_t* out_amax, void* stream) {
+  SEA_CHECK_ARG(partial && C && splits >= 1 && M > 0 && N > 0 && (N % 4) == 0 && ldc >= N && (ldc % 4) == 0);
+  SEA_CHECK_ARG(((((uintptr_t)partial) | ((uintptr_t)C) | ((uintptr_t)bias)) & 15) == 0);
+  const int64_t total = (int64_t)M * (N / 4);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)partial,
+                     splits, total, M, N / 4, (const f32x4*)bias, relu, C, ldc, out_amax);
+  SEA_RETURN_LAST();
+}
+
+extern "C" int sea_absmax_bits(const float* A, int64_t lda, int M, int K, int batch, int64_t strideA, int rows_per_word,
+                               uint32_t* out_bits, void* stream) {
   SEA_CHECK_ARG(A && out_bits && M > 0 && K > 0 && (K % 4) == 0 && (lda % 4) == 0 && batch > 0 && (((uintptr_t)A) & 15) == 0);
-  hipMemsetAsync(out_bits, 0, 4, (hipStream_t)stream);
+  SEA_CHECK_ARG(rows_per_word >= 0);
+  if (rows_per_word > 0 && rows_per_word < M) {
+    // one word per group of rows_per_word consecutive rows (all batch entries): grid.y = group
+    const int words = (M + rows_per_word - 1) / rows_per_word;
+    SEA_CHECK_ARG(words <= 65535);
+    hipLaunchKernelGGL(zero_words_kernel, dim3((words + 255) / 256), dim3(256), 0, (hipStream_t)stream, out_bits, words);
+    const int64_t per = (int64_t)rows_per_word * (K / 4);
+    int gx = (int)((per + 1023) / 1024);
+    gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+    hipLaunchKernelGGL(absmax_groups_kernel, dim3(gx, words), dim3(256), 0, (hipStream_t)stream, A, lda, M, K / 4, strideA, batch,
+                       rows_per_word, out_bits);
+    SEA_RETURN_LAST();
+  }
+  hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out_bits, 1);
   const int64_t total = (int64_t)batch * M * (K / 4);
   int grid = grid_for(total, 512);   // two float4 per lane and trip
   if (grid > 1024) grid = 1024;
@@ -521,7 +705,8 @@ extern "C" int sea_absmax_bits(const float* A, int64_t lda, int M, int K, int ba
 
 static int gemm_split_impl(const float* A, int64_t lda, const void* Wp, float* C, int64_t ldc, const float* bias, int relu, int M,
                            int N, int K, int terms, int batch, int64_t strideA, int64_t strideW_bytes, int64_t strideC,
-                           const uint32_t* amax_bits, void* stream) {
+                           const uint32_t* amax_bits, int amax_rows, uint32_t* out_amax, void* stream,
+                           const SeaGemmEpilogue* epi) {
   SEA_CHECK_ARG(A && Wp && C && M > 0 && N > 0 && K > 0 && (K % GS_BK) == 0 && batch > 0);
   SEA_CHECK_ARG(lda >= K && ldc >= N && (lda % 4) == 0 && (int64_t)M * lda < (1ll << 30));  // 32-bit lane offsets into A
   SEA_CHECK_ARG(((((uintptr_t)A) | ((uintptr_t)Wp)) & 15) == 0 && (((uintptr_t)C) & 3) == 0 && (strideA % 4) == 0 &&
@@ -548,6 +733,13 @@ static int gemm_split_impl(const float* A, int64_t lda, const void* Wp, float* C
   p.per_xcd = (p.total + 7) / 8;
   p.relu = relu;
   p.amax_bits = amax_bits;
+  p.amax_rows = amax_rows;
+  p.out_amax = out_amax;
+  p.addend = epi ? epi->addend : nullptr;
+  p.ld_add = epi ? epi->ld_addend : 0;
+  p.stride_add = epi ? epi->stride_addend : 0;
+  p.gelu_out = epi ? epi->gelu_out : nullptr;
+  p.gelu_grad_of = epi ? epi->gelu_grad_of : nullptr;
   p.w_inv = terms == 22 ? (const float*)((const char*)Wp + (int64_t)(K / GS_BK) * 2 * gs_npad(N) * GS_BK * 2) : nullptr;
   const dim3 grid(p.per_xcd * 8), block(256);
   // MFMA shape: v_mfma_f32_32x32x16_bf16 fragments (default); SEA_GEMM_SHAPE=16 selects v_mfma_f32_16x16x32_bf16
@@ -556,17 +748,25 @@ static int gemm_split_impl(const float* A, int64_t lda, const void* Wp, float* C
     const char* e = getenv("SEA_GEMM_SHAPE");
     return (e && e[0] == '1') ? 1 : 0;
   }();
+  const bool fused = p.addend || p.gelu_out || p.gelu_grad_of;   // (32 x 32 fragments only)
   if (terms == 22) {
-    hipLaunchKernelGGL((gemm_split_kernel<2, false, true>), grid, block, 0, (hipStream_t)stream, p);
+    if (fused)
+      hipLaunchKernelGGL((gemm_split_kernel<2, false, true, true>), grid, block, 0, (hipStream_t)stream, p);
+    else
+      hipLaunchKernelGGL((gemm_split_kernel<2, false, true>), grid, block, 0, (hipStream_t)stream, p);
     SEA_RETURN_LAST();
   }
   if (terms == 3) {
-    if (shape16)
+    if (fused)
+      hipLaunchKernelGGL((gemm_split_kernel<3, false, false, true>), grid, block, 0, (hipStream_t)stream, p);
+    else if (shape16)
       hipLaunchKernelGGL((gemm_split_kernel<3, true>), grid, block, 0, (hipStream_t)stream, p);
     else
       hipLaunchKernelGGL((gemm_split_kernel<3, false>), grid, block, 0, (hipStream_t)stream, p);
   } else {
-    if (shape16)
+    if (fused)
+      hipLaunchKernelGGL((gemm_split_kernel<2, false, false, true>), grid, block, 0, (hipStream_t)stream, p);
+    else if (shape16)
       hipLaunchKernelGGL((gemm_split_kernel<2, true>), grid, block, 0, (hipStream_t)stream, p);
     else
       hipLaunchKernelGGL((gemm_split_kernel<2, false>), grid, block, 0, (hipStream_t)stream, p);

@@ -88,9 +88,12 @@ template <int M, int VEC>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, const float* __restrict__ gate,
                                                          const float* __restrict__ scale, float* __restrict__ V, int C,
                                                          int H, int W, int nTh, int nTw, int64_t T, int64_t total,
-                                                         int64_t xps, int64_t vts, int xcd, Divs3 dv) {
+                                                         int64_t xps, int64_t vts, int xcd, Divs3 dv,
+                                                         uint32_t* __restrict__ amax_out) {
   constexpr int A = M + 2;
   const bool fast = total < kFastIndexLimit;
+  // amax_out != NULL: amax_out[t] receives the float bits of max |V[.][t][.]| of tile t (one word per row of the Winograd-
+  // domain GEMMs = the row's fp16 x 2 scale; a tile's scale depends on that tile only)
   // plain order by default: the transform writes 2.25x what it reads, and the XCD-contiguous order measured 4-9 %
   // slower (profiles/r2_xcd_order_ab.log); SEA_XCD_ORDER=2 turns it on for this kernel
   const IndexRange rg = xcd_range(total, xcd);
@@ -138,6 +141,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
       }
     // columns: v = tmp B, streamed out as soon as each element is ready
     float* vb = V + t * vts + (int64_t)cg * VEC;  // V may be a channel slice of a wider (A*A, T, vts) tensor
+    uint32_t vmax = 0;
 #pragma unroll
     for (int i = 0; i < A; ++i)
 #pragma unroll
@@ -147,7 +151,28 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 #pragma unroll
         for (int k = 0; k < A; ++k) axpy<VEC>(wino_bt(M, j, k), tmp[i][k], v, first);
         vstore<VEC>(vb + (int64_t)(i * A + j) * T * vts, v);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const uint32_t b = __float_as_uint(v[e]) & 0x7fffffffu;
+          vmax = b > vmax ? b : vmax;
+        }
       }
+    if (amax_out != nullptr) {   // kernel-uniform
+      // the 64 lanes of a wave are 64 consecutive channel groups: one tile when C / VEC is a multiple of 64 (every layer of
+      // the UperNet head) -> one atomic per wave; otherwise (or in a partially active wave) one per lane
+      const int ti = (int)t;
+      const bool whole = __ballot(1) == ~0ull && __all(ti == __shfl(ti, 0, 64));
+      if (whole) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const uint32_t other = (uint32_t)__shfl_xor((int)vmax, o, 64);
+          vmax = other > vmax ? other : vmax;
+        }
+        if ((threadIdx.x & 63) == 0) atomicMax(amax_out + t, vmax);
+      } else {
+        atomicMax(amax_out + t, vmax);
+      }
+    }
   }
 }
 
@@ -273,9 +298,26 @@ extern "C" int64_t sea_wino_tiles(int B, int H, int W, int m) {
   return (int64_t)B * ((H + m - 1) / m) * ((W + m - 1) / m);
 }
 
+static int wino_input_impl(const float* x, int64_t x_pixel_stride, const float* gate, const float* scale, float* V,
+                           int64_t v_tile_stride, int B, int C, int H, int W, int m, uint32_t* amax_out, void* stream);
+
 extern "C" int sea_wino_input_transform(const float* x, int64_t x_pixel_stride, const float* gate, const float* scale,
                                         float* V, int64_t v_tile_stride, int B, int C, int H, int W, int m,
                                         void* stream) {
+  return wino_input_impl(x, x_pixel_stride, gate, scale, V, v_tile_stride, B, C, H, W, m, nullptr, stream);
+}
+
+// same, and the float bits of max |V| are max-accumulated into *amax_out (a pre-zeroed device word; several calls that fill
+// channel slices of one V may share it): the activation scale of sea_gemm_split_f16 without another pass over V
+extern "C" int sea_wino_input_transform_amax(const float* x, int64_t x_pixel_stride, const float* gate, const float* scale,
+                                             float* V, int64_t v_tile_stride, int B, int C, int H, int W, int m,
+                                             uint32_t* amax_out, void* stream) {
+  SEA_CHECK_ARG(amax_out != nullptr);
+  return wino_input_impl(x, x_pixel_stride, gate, scale, V, v_tile_stride, B, C, H, W, m, amax_out, stream);
+}
+
+static int wino_input_impl(const float* x, int64_t x_pixel_stride, const float* gate, const float* scale, float* V,
+                           int64_t v_tile_stride, int B, int C, int H, int W, int m, uint32_t* amax_out, void* stream) {
   int nTh, nTw;
   int64_t T;
   SEA_CHECK_ARG(x && V && wino_dims(B, C, H, W, m, 4, &nTh, &nTw, &T));
@@ -285,11 +327,13 @@ extern "C" int sea_wino_input_transform(const float* x, int64_t x_pixel_stride, 
   if (m == 2) {
     const int64_t total = T * (C / 4);
     hipLaunchKernelGGL((wino_input_kernel<2, 4>), dim3(grid_for_xcd(total, 256)), dim3(256), 0, (hipStream_t)stream, x, gate,
-                       scale, V, C, H, W, nTh, nTw, T, total, x_pixel_stride, v_tile_stride, xcd_order_enabled() == 2, divs3(C / 4, nTw, nTh));
+                       scale, V, C, H, W, nTh, nTw, T, total, x_pixel_stride, v_tile_stride, xcd_order_enabled() == 2, divs3(C / 4, nTw, nTh),
+                       amax_out);
   } else {
     const int64_t total = T * (C / 2);
     hipLaunchKernelGGL((wino_input_kernel<4, 2>), dim3(grid_for_xcd(total, 256)), dim3(256), 0, (hipStream_t)stream, x, gate,
-                       scale, V, C, H, W, nTh, nTw, T, total, x_pixel_stride, v_tile_stride, xcd_order_enabled() == 2, divs3(C / 2, nTw, nTh));
+                       scale, V, C, H, W, nTh, nTw, T, total, x_pixel_stride, v_tile_stride, xcd_order_enabled() == 2, divs3(C / 2, nTw, nTh),
+                       amax_out);
   }
   SEA_RETURN_LAST();
 }

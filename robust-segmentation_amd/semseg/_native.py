@@ -72,8 +72,11 @@ _SIGS = {
                                _i64, _i64, _i64, _vp]),
     "sea_attention_bwd_terms": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _i64, _i64, _i64, _i, _vp]),
-    "sea_absmax_bits": (_i, [_vp, _i64, _i, _i, _i, _i64, _vp, _vp]),
-    "sea_gemm_split_f16": (_i, [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _i, _i64, _i64, _i64, _vp, _vp]),
+    "sea_absmax_bits": (_i, [_vp, _i64, _i, _i, _i, _i64, _i, _vp, _vp]),
+    "sea_gemm_split_f16": (_i, [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _i, _i64, _i64, _i64, _vp, _i, _vp, _vp]),
+    "sea_wino_input_transform_amax": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp]),
+    "sea_gemm_split_fused": (_i, [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _vp, _i, _vp, _vp, _vp]),
+    "sea_gemm_splitk_reduce": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i64, _vp, _vp]),
     "sea_gemm_split_packed_bytes": (_i64, [_i, _i, _i]),
     "sea_gemm_split_pack": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp]),
     "sea_gemm_split": (_i, [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _vp]),
@@ -541,17 +544,25 @@ def wino_conv3x3_cl(x, U, m: int, bias=None, scale=None, relu: bool = False, gat
     T = L.sea_wino_tiles(B, H, W, m)
     V = torch.empty(A2, T, Cin, dtype=torch.float32, device=xs[0].device)
     off = 0
+    use_split = gemm_terms in (2, 3, 22) and Cin % 32 == 0 and T >= 256
+    # fp16 x 2: one scale word per tile (= per row of the Winograd-domain GEMMs), filled by the transform itself
+    v_amax = (torch.zeros(T, dtype=torch.int32, device=xs[0].device)
+              if (use_split and gemm_terms == 22 and AMAX_FROM_PRODUCERS) else None)
     for t, xps in zip(xs, strides):
-        _check(L.sea_wino_input_transform(_p(t), xps, _p(gate), _p(gate_scale), V.data_ptr() + 4 * off, Cin, B, t.shape[1],
-                                          H, W, m, _stream()), "sea_wino_input_transform")
+        if v_amax is not None:
+            _check(L.sea_wino_input_transform_amax(_p(t), xps, _p(gate), _p(gate_scale), V.data_ptr() + 4 * off, Cin, B,
+                                                   t.shape[1], H, W, m, _p(v_amax), _stream()), "sea_wino_input_transform_amax")
+        else:
+            _check(L.sea_wino_input_transform(_p(t), xps, _p(gate), _p(gate_scale), V.data_ptr() + 4 * off, Cin, B, t.shape[1],
+                                              H, W, m, _stream()), "sea_wino_input_transform")
         off += t.shape[1]
-    if gemm_terms in (2, 3, 22) and Cin % 32 == 0 and T >= 256:
+    if use_split:
         # M8: the (A*A) Winograd-domain products on the bf16 matrix cores (operands split into bf16 terms, fp32 accumulate)
         packed = U.__dict__.setdefault("_sea_packed", {})   # U is the cached, frozen filter image: packed once per term count
         Up = packed.get(gemm_terms)
         if Up is None:
             Up = packed[gemm_terms] = gemm_split_pack(U, trans=True, terms=gemm_terms)
-        Mx = gemm_split(V, Up)
+        Mx = gemm_split(V, Up, amax=v_amax, amax_rows=1 if v_amax is not None else 0, groups=B)
     else:
         with torch.autocast("cuda", enabled=False):
             Mx = _f32c(torch.bmm(V, U))  # (A*A) independent fp32 GEMMs: hipBLASLt strided-batched
@@ -676,9 +687,19 @@ class PackedWeight:
     """Frozen weights W (N x K) pre-split into `terms` bf16 images in the tile order of sea_gemm_split
     (optionally a batch of them, e.g. the (m+2)^2 Winograd-domain filters)."""
 
-    def __init__(self, data, N, K, terms, batch):
+    def __init__(self, data, N, K, terms, batch, src=None):
         self.data, self.N, self.K, self.terms, self.batch = data, N, K, terms, batch
         self.stride = data.numel() // batch
+        self.src = src          # (W, trans) of a single matrix: K slices are packed from it on demand (split-K)
+        self.slices = {}
+
+    def k_slices(self, S):
+        """this weight as a batch of S packed (N x K/S) matrices, one per K slice"""
+        if S not in self.slices:
+            W, trans = self.src
+            Ws = W.view(S, self.K // S, self.N) if trans else W.view(self.N, S, self.K // S).permute(1, 0, 2)
+            self.slices[S] = gemm_split_pack(Ws, trans=trans, terms=self.terms)
+        return self.slices[S]
 
 
 def gemm_split_pack(W, trans: bool = False, terms: int = 3) -> PackedWeight:
@@ -697,13 +718,103 @@ def gemm_split_pack(W, trans: bool = False, terms: int = 3) -> PackedWeight:
     for g in range(G):
         _check(L.sea_gemm_split_pack(_p(Wb[g]), Wb.stride(1), int(trans), N, K, terms, _p(out[g]), _stream()),
                "sea_gemm_split_pack")
-    return PackedWeight(out, N, K, terms, G)
+    return PackedWeight(out, N, K, terms, G, src=(W.detach(), trans) if (W.dim() == 2 and W.is_contiguous()) else None)
 
 
-def gemm_split(A, Wp: PackedWeight, bias=None, relu: bool = False, out=None):
+class AmaxPool:
+    """Zero-initialised 4-byte device words that producers max-accumulate |x| bits into (atomicMax needs a zeroed word)
+    and fp16 x 2 GEMMs read their activation scale from.  One small tensor per device, re-zeroed with ONE fill per model
+    forward (``reset``) instead of one memset per GEMM; words are handed out in call order, so a HIP-graph replay of the
+    same forward touches the same words."""
+    _pools = {}
+    SIZE = 1024
+
+    def __init__(self, device):
+        self.buf = torch.zeros(self.SIZE, dtype=torch.int32, device=device)
+        self.next = 0
+
+    @classmethod
+    def get(cls, device):
+        device = torch.device(device)
+        key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+        if key not in cls._pools:
+            cls._pools[key] = AmaxPool(device)
+        return cls._pools[key]
+
+    def reset(self):
+        self.buf.zero_()
+        self.next = 0
+
+    def word(self):
+        if self.next >= self.SIZE:      # more GEMMs than words since the last reset: a FRESH zeroed buffer (words that
+            self.buf = torch.zeros(self.SIZE, dtype=torch.int32, device=self.buf.device)   # were handed out stay valid)
+            self.next = 0
+        w = self.buf[self.next:self.next + 1]
+        self.next += 1
+        return w
+
+
+# A/B switch (env SEA_AMAX_FUSE=0): every fp16 x 2 GEMM computes max|A| with its own pass instead of taking it from the producer
+AMAX_FROM_PRODUCERS = os.environ.get("SEA_AMAX_FUSE", "1") != "0"
+
+
+def amax_word(device):
+    return AmaxPool.get(device).word()
+
+
+# split-K (env SEA_GEMM_KSPLIT=0 disables): GEMMs with fewer than KSPLIT_BELOW 128 x 128 tiles and a long K run as a batch
+# of K slices + sea_gemm_splitk_reduce
+KSPLIT = os.environ.get("SEA_GEMM_KSPLIT", "1") != "0"
+KSPLIT_BELOW, KSPLIT_TARGET, KSPLIT_MIN_KB = (int(v) for v in os.environ.get("SEA_GEMM_KSPLIT_PARAMS", "400,768,8").split(","))
+_ksplit_ws = {}
+
+
+def _ksplit(M, N, K):
+    blocks = -(-M // 128) * -(-N // 128)
+    nkb = K // 32
+    if not KSPLIT or blocks >= KSPLIT_BELOW or N % 4:
+        return 1
+    S = min(-(-KSPLIT_TARGET // blocks), nkb // KSPLIT_MIN_KB)
+    while S > 1 and nkb % S:
+        S -= 1
+    return max(S, 1)
+
+
+def _ksplit_workspace(device, numel):
+    """(splits, M, N) partial products: one buffer per device and stream, grown on demand (a HIP-graph capture sees the
+    buffer of its capture stream, allocated by the eager iteration that runs on that stream first)"""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _ksplit_ws.get(key)
+    if ws is None or ws.numel() < numel:
+        ws = _ksplit_ws[key] = torch.empty(numel, dtype=torch.float32, device=device)
+    return ws[:numel]
+
+
+class _GemmEpilogue(C.Structure):       # SeaGemmEpilogue of include/sea_hip.h
+    _fields_ = [("addend", C.c_void_p), ("ld_addend", C.c_int64), ("stride_addend", C.c_int64),
+                ("gelu_out", C.c_void_p), ("gelu_grad_of", C.c_void_p)]
+
+
+def _amax_words(A3, M, K, G, sA, groups):
+    """exact per-group maxima of |A| (float bits), one word per M / groups rows"""
+    rpw = M // groups if (groups > 1 and M % groups == 0) else 0
+    words = torch.empty(groups if rpw else 1, dtype=torch.int32, device=A3.device)
+    _check(lib().sea_absmax_bits(_p(A3), A3.stride(1), M, K, G, sA, rpw, _p(words), _stream()), "sea_absmax_bits")
+    return words, rpw
+
+
+def gemm_split(A, Wp: PackedWeight, bias=None, relu: bool = False, out=None, amax=None, out_amax=None, addend=None,
+               gelu_out=None, gelu_grad_of=None, amax_rows: int = 0, groups: int = 1):
     """out (.., N) = A (.., K) @ W^T [+ bias] [ReLU] with W pre-split (``gemm_split_pack``).  A: fp32, last dim
-    contiguous; 2-D (M, K) with any 4-aligned row stride, or (G, M, K) against a batch of G packed weights."""
-    _dev(A, bias, out)
+    contiguous; 2-D (M, K) with any 4-aligned row stride, or (G, M, K) against a batch of G packed weights.
+    fp16 x 2 weights (terms 22): ``amax`` = device words holding the float bits of (upper bounds of) max|A|, one per
+    ``amax_rows`` rows (0: one word for the tensor); computed here when None, one word per ``groups``-th of the rows (pass
+    the number of images: an image's scale then does not depend on its batch partners); ``out_amax`` = pre-zeroed word that
+    receives the bits of max|out|.
+    Fused epilogue (sea_gemm_split_fused): ``addend`` (shape of out, last dim contiguous) is added before the activation;
+    ``gelu_out`` (layout of out) receives GELU(out) while out keeps the pre-activation; the result is multiplied by
+    GELU'(``gelu_grad_of``) (layout of out)."""
+    _dev(A, bias, out, addend, gelu_out, gelu_grad_of)
     batched = Wp.batch > 1 or A.dim() == 3
     A3 = A if A.dim() == 3 else A.unsqueeze(0)
     if (A.dtype != torch.float32 or A3.dim() != 3 or A3.shape[0] != Wp.batch or A3.shape[2] != Wp.K
@@ -718,12 +829,48 @@ def gemm_split(A, Wp: PackedWeight, bias=None, relu: bool = False, out=None):
     if bias is not None and (bias.dtype != torch.float32 or bias.numel() != Wp.N or not bias.is_contiguous()):
         raise SeaNativeError("gemm_split: bias must be contiguous float32 of N entries")
     sA, sC = (A3.stride(0) if G > 1 else 0), (O3.stride(0) if G > 1 else 0)
+    if amax is not None and (amax.dtype != torch.int32 or not amax.is_contiguous()
+                             or amax.numel() < (-(-M // amax_rows) if amax_rows > 0 else 1)):
+        raise SeaNativeError("gemm_split: amax must hold one int32 word per amax_rows rows")
+    fused = addend is not None or gelu_out is not None or gelu_grad_of is not None
+    if G == 1 and not fused and Wp.src is not None and O3.stride(1) % 4 == 0 and O3.data_ptr() % 16 == 0:
+        S = _ksplit(M, Wp.N, K)
+        if S > 1:
+            if Wp.terms == 22 and amax is None:
+                amax, amax_rows = _amax_words(A3, M, K, 1, 0, groups)
+            part = _ksplit_workspace(A.device, S * M * Wp.N).view(S, M, Wp.N)
+            gemm_split(A3[0].as_strided((S, M, K // S), (K // S, A3.stride(1), 1)), Wp.k_slices(S), out=part, amax=amax,
+                       amax_rows=amax_rows)
+            _check(lib().sea_gemm_splitk_reduce(_p(part), S, M, Wp.N, _p(bias), int(relu), _p(O3), O3.stride(1),
+                                                _p(out_amax) if Wp.terms == 22 else None, _stream()), "sea_gemm_splitk_reduce")
+            return out
+    if fused:
+        epi = _GemmEpilogue()
+        if addend is not None:
+            D3 = addend if addend.dim() == 3 else addend.unsqueeze(0)
+            if D3.shape != O3.shape or D3.stride(2) != 1 or addend.dtype != torch.float32:
+                raise SeaNativeError("gemm_split: addend must be float32 of the output's shape with a contiguous last dim")
+            epi.addend, epi.ld_addend, epi.stride_addend = D3.data_ptr(), D3.stride(1), (D3.stride(0) if G > 1 else 0)
+        for name, t in (("gelu_out", gelu_out), ("gelu_grad_of", gelu_grad_of)):
+            if t is not None:
+                T3 = t if t.dim() == 3 else t.unsqueeze(0)
+                if T3.shape != O3.shape or T3.stride() != O3.stride() or t.dtype != torch.float32:
+                    raise SeaNativeError(f"gemm_split: {name} must be float32 with the output's shape and strides")
+                setattr(epi, name, T3.data_ptr())
+        if Wp.terms == 22 and amax is None:
+            amax, amax_rows = _amax_words(A3, M, K, G, sA, groups)
+        _check(lib().sea_gemm_split_fused(_p(A3), A3.stride(1), _p(Wp.data), _p(O3), O3.stride(1), _p(bias), int(relu), M, Wp.N,
+                                          K, Wp.terms, G, sA, Wp.stride, sC, _p(amax) if Wp.terms == 22 else None, amax_rows,
+                                          _p(out_amax) if Wp.terms == 22 else None, C.addressof(epi), _stream()),
+               "sea_gemm_split_fused")
+        return out
     if Wp.terms == 22:
         # fp16 x 2: the activation scale comes from max|A|, computed on the device (no host round trip)
-        amax = torch.empty(1, dtype=torch.int32, device=A.device)
-        _check(lib().sea_absmax_bits(_p(A3), A3.stride(1), M, K, G, sA, _p(amax), _stream()), "sea_absmax_bits")
+        if amax is None:
+            amax, amax_rows = _amax_words(A3, M, K, G, sA, groups)
         _check(lib().sea_gemm_split_f16(_p(A3), A3.stride(1), _p(Wp.data), _p(O3), O3.stride(1), _p(bias), int(relu), M, Wp.N,
-                                        K, G, sA, Wp.stride, sC, _p(amax), _stream()), "sea_gemm_split_f16")
+                                        K, G, sA, Wp.stride, sC, _p(amax), amax_rows, _p(out_amax), _stream()),
+               "sea_gemm_split_f16")
         return out
     _check(lib().sea_gemm_split(_p(A3), A3.stride(1), _p(Wp.data), _p(O3), O3.stride(1), _p(bias), int(relu), M, Wp.N, K,
                                 Wp.terms, G, sA, Wp.stride, sC, _stream()), "sea_gemm_split")

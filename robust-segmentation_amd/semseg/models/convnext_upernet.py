@@ -274,23 +274,61 @@ def _split_ok(x2d, K, terms=None):
             and x2d.shape[0] >= GEMM_MIN_ROWS and not torch.is_autocast_enabled())
 
 
-def _frozen_mm(x2d, w, cache, name, trans=False, bias=None, relu=False, terms=None):
-    """act(x2d @ W^T + bias) for a FROZEN weight: w is (N, K), or (K, N) with ``trans``.  The packed (pre-split) image
-    of w is cached in ``cache`` under ``name`` (per number of terms) until w changes."""
+def _packed(w, cache, name, trans, terms):
+    """the packed (pre-split) image of the frozen weight w, cached in ``cache`` under ``name`` (per number of terms) until
+    w changes"""
+    from .. import _native as N
+    name = f"{name}_t{terms}"
+    key = (_tkey(w), trans)
+    if cache.get(name + "_key") != key:
+        with torch.no_grad():
+            cache[name] = N.gemm_split_pack(w.detach(), trans=trans, terms=terms)
+        cache[name + "_key"] = key
+    return cache[name]
+
+
+def _frozen_mm(x2d, w, cache, name, trans=False, bias=None, relu=False, terms=None, amax=None, out_amax=None, groups=1):
+    """act(x2d @ W^T + bias) for a FROZEN weight: w is (N, K), or (K, N) with ``trans``.  ``groups`` = number of images
+    the rows of x2d belong to (image-major): without a supplied ``amax`` the fp16 x 2 mode scales every image by its own
+    maximum, so that an image's result does not depend on its batch partners."""
     K = w.shape[0] if trans else w.shape[1]
     terms = _terms() if terms is None else terms
     if _split_ok(x2d, K, terms):
         from .. import _native as N
-        name = f"{name}_t{terms}"
-        key = (_tkey(w), trans)
-        if cache.get(name + "_key") != key:
-            with torch.no_grad():
-                cache[name] = N.gemm_split_pack(w.detach(), trans=trans, terms=terms)
-            cache[name + "_key"] = key
-        return N.gemm_split(x2d, cache[name], bias=bias, relu=relu)
+        if terms != 22:
+            amax = out_amax = None
+        return N.gemm_split(x2d, _packed(w, cache, name, trans, terms), bias=bias, relu=relu, amax=amax, out_amax=out_amax,
+                            groups=groups)
     wt = w if trans else w.t()
     y = torch.addmm(bias, x2d, wt) if bias is not None else x2d @ wt
     return torch.relu_(y) if relu else y
+
+
+def _ln_bound_word(norm, cache):
+    """float bits (int32 device word) of sqrt(C) max|w| + max|b|: an upper bound of |LayerNorm(x)| for ANY x
+    (|(x - mean) * rstd| <= sqrt(C - 1)), used as the fp16 x 2 activation scale of the GEMM that consumes the
+    LayerNorm's output: no pass over the activations.  Cached until the affine parameters change."""
+    key = _tkey(norm.weight, norm.bias)
+    if cache.get("ln_bound_key") != key:
+        with torch.no_grad():
+            bnd = norm.weight.numel() ** 0.5 * norm.weight.abs().max() + norm.bias.abs().max()
+            cache.update(ln_bound_key=key, ln_bound=bnd.float().reshape(1).contiguous().view(torch.int32))
+    return cache["ln_bound"]
+
+
+def _linear_bound_word(in_word, w, b, cache):
+    """float bits of max_n (bound(x) ||W_n||_1 + |b_n|): an upper bound of |x W^T + b| for any x with |x| <= bound(x)
+    (``in_word``: float bits of that bound), hence of GELU / ReLU of it and of any convex combination of its rows (attention).
+    The fp16 x 2 scale of the NEXT GEMM without a pass over the activations and without any dependence on the batch.
+    Cached until the weights change."""
+    key = (_tkey(w, b), in_word.data_ptr())
+    if cache.get("lin_bound_key") != key:
+        with torch.no_grad():
+            bnd = in_word.view(torch.float32) * w.abs().sum(1)
+            if b is not None:
+                bnd = bnd + b.abs()
+            cache.update(lin_bound_key=key, lin_bound=bnd.max().float().reshape(1).contiguous().view(torch.int32))
+    return cache["lin_bound"]
 
 
 class _FrozenLinear(torch.autograd.Function):
@@ -298,10 +336,11 @@ class _FrozenLinear(torch.autograd.Function):
 
     @staticmethod
     @_fp32_fwd
-    def forward(ctx, x, w, b, cache):
+    def forward(ctx, x, w, b, cache, amax=None, out_amax=None):
         ctx.w, ctx.cache, ctx.shape, ctx.terms = w, cache, x.shape, _terms()
         x2 = x.reshape(-1, x.shape[-1])
-        return _frozen_mm(x2, w, cache, "lin_fwd", bias=b).view(*x.shape[:-1], w.shape[0])
+        return _frozen_mm(x2, w, cache, "lin_fwd", bias=b, amax=amax, out_amax=out_amax,
+                          groups=x.shape[0] if x.dim() > 2 else 1).view(*x.shape[:-1], w.shape[0])
 
     @staticmethod
     @_fp32_bwd
@@ -309,16 +348,87 @@ class _FrozenLinear(torch.autograd.Function):
         g2 = gy.reshape(-1, gy.shape[-1])
         if not g2.is_contiguous():
             g2 = g2.contiguous()
-        return _frozen_mm(g2, ctx.w, ctx.cache, "lin_bwd", trans=True, terms=_bwd_terms(ctx.terms)).view(ctx.shape), None, None, None
+        return (_frozen_mm(g2, ctx.w, ctx.cache, "lin_bwd", trans=True, terms=_bwd_terms(ctx.terms),
+                           groups=ctx.shape[0] if len(ctx.shape) > 2 else 1).view(ctx.shape), None, None, None, None, None)
 
 
-def _linear_frozen(mod_cache, x, w, b):
-    """F.linear through M8 when the weights are frozen and the shape qualifies; plain F.linear otherwise."""
+def _linear_frozen(mod_cache, x, w, b, amax=None, out_amax=None):
+    """F.linear through M8 when the weights are frozen and the shape qualifies; plain F.linear otherwise.
+    ``amax`` / ``out_amax``: device words for the fp16 x 2 mode (see _native.gemm_split): an upper bound of max|x| supplied
+    by the producer instead of a pass over x, and a pre-zeroed word that receives max|output|."""
     if (_terms() in (2, 3, 22) and x.is_cuda and x.dtype == torch.float32 and not w.requires_grad
             and (b is None or not b.requires_grad) and w.shape[1] % 32 == 0 and not torch.is_autocast_enabled()
             and x.is_contiguous() and x.numel() // x.shape[-1] >= GEMM_MIN_ROWS):
-        return _FrozenLinear.apply(x, w, b, mod_cache)
+        return _FrozenLinear.apply(x, w, b, mod_cache, amax, out_amax)
     return F.linear(x, w, b)
+
+
+# Element-wise neighbours of a block's MLP in the GEMM epilogues (sea_gemm_split_fused).  Bit mask: 1 = GELU in the first
+# forward GEMM's epilogue, 2 = GELU' in the first backward GEMM's, 4 = residual add in the second forward GEMM's.
+# MEASURED SLOWER on MI355X and therefore OFF by default (UperNet-ConvNeXt-T, B=8, 512x512, ms per APGD step:
+# 0: 18.16, 1: 18.24, 4: 18.59, 2: 18.97, 7: 19.32): the separate ATen passes stream from the 256 MiB Infinity Cache
+# at full occupancy, while the same loads / erf evaluations in the epilogue of a short-K GEMM run at 3 waves per SIMD
+# behind the accumulators (64 scalar accesses per lane).  Kept as a tested option of the C ABI.
+FUSE_MLP = int(os.environ.get("SEA_FUSE_MLP", "0"))
+
+
+def _mlp_fusable(x, w1, b1, w2, b2):
+    """both projections of a block's MLP qualify for M8 (frozen weights, fp32 HIP tensor, shapes): the pair runs as two
+    GEMMs with GELU, GELU' and the residual add in their epilogues (_FrozenMlp)"""
+    return (FUSE_MLP and _terms() in (2, 3, 22) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+            and not torch.is_autocast_enabled() and x.numel() // x.shape[-1] >= GEMM_MIN_ROWS
+            and w1.shape[1] % 32 == 0 and w2.shape[1] % 32 == 0 and w2.shape[0] == x.shape[-1]
+            and not any(t is not None and t.requires_grad for t in (w1, b1, w2, b2)))
+
+
+class _FrozenMlp(torch.autograd.Function):
+    """res + W2 GELU(W1 x + b1) + b2 for frozen (W1, b1, W2, b2) (the MLP of a ConvNeXt / ViT block, reference
+    convnext_orig.py:38-58, vit_encoder.py:41-60), input gradient only.  Two M8 GEMMs each way; GELU runs in the epilogue
+    of the first forward GEMM (which keeps the pre-activation for the backward), GELU' in the epilogue of the first
+    backward GEMM, the residual add in the epilogue of the second forward GEMM: no element-wise pass over the 4C-wide
+    hidden tensor in either direction."""
+
+    @staticmethod
+    @_fp32_fwd
+    def forward(ctx, x, w1, b1, w2, b2, res, caches, a1, a2):
+        from .. import _native as N
+        terms = _terms()
+        x2 = x.reshape(-1, x.shape[-1])
+        if terms != 22:
+            a1 = a2 = None
+        t = torch.empty(x2.shape[0], w1.shape[0], dtype=torch.float32, device=x.device)
+        fuse, nb = int(FUSE_MLP), (x.shape[0] if x.dim() > 2 else 1)
+        r2 = None if res is None else res.reshape(-1, res.shape[-1])
+        if fuse & 1:
+            h = torch.empty_like(t)
+            N.gemm_split(x2, _packed(w1, caches[0], "lin_fwd", False, terms), bias=b1, out=t, gelu_out=h, amax=a1, groups=nb)
+        else:
+            N.gemm_split(x2, _packed(w1, caches[0], "lin_fwd", False, terms), bias=b1, out=t, amax=a1, groups=nb)
+            h = F.gelu(t)
+        y = N.gemm_split(h, _packed(w2, caches[1], "lin_fwd", False, terms), bias=b2, amax=a2, addend=r2 if fuse & 4 else None,
+                         groups=nb)
+        if r2 is not None and not fuse & 4:
+            y += r2
+        ctx.fuse = fuse
+        ctx.save_for_backward(t)
+        ctx.w, ctx.caches, ctx.shape, ctx.terms, ctx.has_res = (w1, w2), caches, x.shape, terms, res is not None
+        return y.view(x.shape)
+
+    @staticmethod
+    @_fp32_bwd
+    def backward(ctx, g):
+        from .. import _native as N
+        (t,) = ctx.saved_tensors
+        terms = _bwd_terms(ctx.terms)
+        g2 = g.reshape(-1, g.shape[-1])
+        if not g2.is_contiguous():
+            g2 = g2.contiguous()
+        if ctx.fuse & 2:
+            gh = N.gemm_split(g2, _packed(ctx.w[1], ctx.caches[1], "lin_bwd", True, terms), gelu_grad_of=t)
+        else:
+            gh = torch.ops.aten.gelu_backward(N.gemm_split(g2, _packed(ctx.w[1], ctx.caches[1], "lin_bwd", True, terms)), t)
+        gx = N.gemm_split(gh, _packed(ctx.w[0], ctx.caches[0], "lin_bwd", True, terms))
+        return gx.view(ctx.shape), None, None, None, None, (g if ctx.has_res else None), None, None, None
 
 
 def _taps_major(conv: nn.Conv2d):
@@ -433,17 +543,35 @@ class Block(nn.Module):
             # (skip, y): the skip gradient is added inside the depthwise backward kernel
             xn, y = _DwConv7x7NHWCSkip.apply(xn, self.dwconv.weight, self.dwconv.bias, _taps_major(self.dwconv))
             gc = self.__dict__.setdefault("_gemm_cache", ({}, {}))
-            y = self.act(_linear_frozen(gc[0], self.norm(y), self.pwconv1.weight, self.pwconv1.bias))
+            # fp16 x 2 GEMMs take their activation scale from analytic bounds (no pass over the activations, no dependence on
+            # the batch): sqrt(C) max|w| + max|b| for the LayerNorm's output, and its image under the first projection for
+            # GELU's (|GELU(t)| <= |t|)
+            a1 = a2 = None
+            from .. import _native as N
+            if (_terms() == 22 and N.AMAX_FROM_PRODUCERS
+                    and not (self.norm.weight.requires_grad or self.norm.bias.requires_grad
+                             or self.pwconv1.weight.requires_grad or self.pwconv1.bias.requires_grad)):
+                a1 = _ln_bound_word(self.norm, gc[0])
+                a2 = _linear_bound_word(a1, self.pwconv1.weight, self.pwconv1.bias, gc[0])
             w2, b2, g = self.pwconv2.weight, self.pwconv2.bias, self.gamma
-            if g is not None and not (w2.requires_grad or g.requires_grad or (b2 is not None and b2.requires_grad)):
+            folded = g is not None and not (w2.requires_grad or g.requires_grad or (b2 is not None and b2.requires_grad))
+            if folded:
                 # frozen weights: the layer scale is folded into the second projection (one kernel less each way)
                 key = _tkey(w2, b2, g)
                 cache = self.__dict__.setdefault("_fold_cache", {})
                 if cache.get("key") != key:
                     with torch.no_grad():
                         cache.update(key=key, w=(w2 * g[:, None]).contiguous(), b=None if b2 is None else b2 * g)
-                y = _linear_frozen(gc[1], y, cache["w"], cache["b"])
+                yn = self.norm(y)
+                if isinstance(self.act, nn.GELU) and self.act.approximate == "none" and _mlp_fusable(
+                        yn, self.pwconv1.weight, self.pwconv1.bias, cache["w"], cache["b"]):
+                    # GELU, GELU' and the residual add in the GEMM epilogues
+                    return _FrozenMlp.apply(yn, self.pwconv1.weight, self.pwconv1.bias, cache["w"], cache["b"], xn, gc, a1,
+                                            a2).permute(0, 3, 1, 2)
+                y = self.act(_linear_frozen(gc[0], yn, self.pwconv1.weight, self.pwconv1.bias, amax=a1))
+                y = _linear_frozen(gc[1], y, cache["w"], cache["b"], amax=a2)
             else:
+                y = self.act(_linear_frozen(gc[0], self.norm(y), self.pwconv1.weight, self.pwconv1.bias, amax=a1))
                 y = self.pwconv2(y)
                 if g is not None:
                     y = g * y
@@ -468,7 +596,7 @@ class _PatchConv2x2(torch.autograd.Function):
     bitwise reproducible; input and output are channels_last, the patch gather is one strided copy each way."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, cache):
+    def forward(ctx, x, weight, bias, cache, amax=None):
         B, C, H, W = x.shape
         key = _tkey(weight)
         if cache.get("key") != key:
@@ -480,7 +608,7 @@ class _PatchConv2x2(torch.autograd.Function):
             patches = N.patch2x2(xn)                                           # one 16-byte-per-lane gather pass
         else:
             patches = xn.reshape(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, 4 * C)
-        y = _frozen_mm(patches, wr, cache, "patch_fwd", bias=bias)
+        y = _frozen_mm(patches, wr, cache, "patch_fwd", bias=bias, amax=amax, groups=B)
         ctx.wr, ctx.shape, ctx.cache, ctx.terms = wr, (B, C, H, W), cache, _terms()
         # under autocast the GEMM ran (and returned) bf16: the trunk's residual stream stays fp32
         return y.float().view(B, H // 2, W // 2, -1).permute(0, 3, 1, 2)       # channels_last (B,Cout,H/2,W/2)
@@ -490,13 +618,13 @@ class _PatchConv2x2(torch.autograd.Function):
         B, C, H, W = ctx.shape
         g = gy.permute(0, 2, 3, 1).reshape(-1, gy.shape[1])
         rows = _frozen_mm(g if g.is_contiguous() else g.contiguous(), ctx.wr, ctx.cache, "patch_bwd", trans=True,
-                          terms=_bwd_terms(ctx.terms)).float()
+                          terms=_bwd_terms(ctx.terms), groups=B).float()
         if C % 4 == 0 and rows.is_contiguous():
             from .. import _native as N
             gp = N.unpatch2x2(rows, B, H, W)
         else:
             gp = rows.view(B, H // 2, W // 2, 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, C)
-        return gp.permute(0, 3, 1, 2), None, None, None
+        return gp.permute(0, 3, 1, 2), None, None, None, None
 
 
 def _patch_conv_ok(conv, x):
@@ -547,7 +675,10 @@ class ConvNeXt(nn.Module):
         for i in range(4):
             ds = self.downsample_layers[i]
             if i > 0 and _patch_conv_ok(ds[1], x):
-                x = _PatchConv2x2.apply(ds[0](x), ds[1].weight, ds[1].bias, ds[1].__dict__.setdefault("_patch_cache", {}))
+                pc = ds[1].__dict__.setdefault("_patch_cache", {})
+                from .. import _native as N
+                ln_ok = _terms() == 22 and N.AMAX_FROM_PRODUCERS and not (ds[0].weight.requires_grad or ds[0].bias.requires_grad)
+                x = _PatchConv2x2.apply(ds[0](x), ds[1].weight, ds[1].bias, pc, _ln_bound_word(ds[0], pc) if ln_ok else None)
             else:
                 x = ds(x)
             if STAGE_ENTRY_CONTIGUOUS and not x.is_contiguous():
@@ -644,17 +775,18 @@ class _PointwiseRelu(torch.autograd.Function):
     the incoming gradient with the output and runs the transposed product."""
 
     @staticmethod
-    def forward(ctx, x2, w, shift, cache):
-        y = _frozen_mm(x2, w, cache, "pw_fwd", bias=shift, relu=True)
+    def forward(ctx, x2, w, shift, cache, groups=1):
+        y = _frozen_mm(x2, w, cache, "pw_fwd", bias=shift, relu=True, groups=groups)
         ctx.save_for_backward(y)
-        ctx.w, ctx.cache, ctx.terms = w, cache, _terms()
+        ctx.w, ctx.cache, ctx.terms, ctx.groups = w, cache, _terms(), groups
         return y
 
     @staticmethod
     def backward(ctx, gy):
         (y,) = ctx.saved_tensors
         g = torch.where(y > 0, gy, torch.zeros((), dtype=gy.dtype, device=gy.device))
-        return _frozen_mm(g, ctx.w, ctx.cache, "pw_bwd", trans=True, terms=_bwd_terms(ctx.terms)), None, None, None
+        return (_frozen_mm(g, ctx.w, ctx.cache, "pw_bwd", trans=True, terms=_bwd_terms(ctx.terms), groups=ctx.groups), None, None,
+                None, None)
 
 
 class ConvModule(nn.Module):
@@ -682,7 +814,7 @@ class ConvModule(nn.Module):
         # would make autograd clone / copy whole tensors in CopySlices)
         x2 = x.permute(0, 2, 3, 1).reshape(B * H * W, -1)
         if _split_ok(x2, x2.shape[1]):
-            y = _PointwiseRelu.apply(x2, cache["pw_w"], shift, cache)
+            y = _PointwiseRelu.apply(x2, cache["pw_w"], shift, cache, B)
         else:
             y = torch.relu_(torch.addmm(shift, x2, cache["pw_w"].t()))
         return y.view(B, H, W, -1).permute(0, 3, 1, 2)
@@ -865,7 +997,7 @@ class _FpnBottleneck(torch.autograd.Function):
         for j, i in enumerate(lo):
             f = _dense_cl(fs[i])
             G = _frozen_mm(f.permute(0, 2, 3, 1).reshape(-1, f.shape[1]), cache["fpn_lo"][j], cache,
-                           f"fpn_lo_fwd{j}").view(B, f.shape[2], f.shape[3], 9, Cout)
+                           f"fpn_lo_fwd{j}", groups=B).view(B, f.shape[2], f.shape[3], 9, Cout)
             extra = N.tap_gather(G, (H, W), extra)
         ctx.terms = _terms()
         y = N.wino_conv3x3_cl(xs, cache["fpn_fwd"], m, bias=shift, scale=scale, relu=True, addend=extra,
@@ -897,7 +1029,7 @@ class _FpnBottleneck(torch.autograd.Function):
                 h, w = shapes[i][2:]
                 dG = N.tap_gather_backward(gz, (h, w))
                 grads[i] = _frozen_mm(dG.view(B * h * w, -1), cache["fpn_lo"][j], cache, f"fpn_lo_bwd{j}", trans=True,
-                                      terms=_bwd_terms(ctx.terms)).view(B, h, w, chans[i]).permute(0, 3, 1, 2)
+                                      terms=_bwd_terms(ctx.terms), groups=B).view(B, h, w, chans[i]).permute(0, 3, 1, 2)
         return (None, None, None, None, None, *grads)
 
 
@@ -1047,12 +1179,20 @@ class UperNetForSemanticSegmentation(nn.Module):
                 return self.decode_head(feats)
         return self.decode_head(feats)
 
+    @staticmethod
+    def _reset_amax_pool(t):
+        if t.is_cuda and GEMM_TERMS == 22:
+            from .. import _native as N
+            N.AmaxPool.get(t.device).reset()
+
     def forward_lowres(self, input):
         """(logits at 1/4 resolution, output size): semseg.attacker fuses the final bilinear upsample
         into its loss kernel (K2u) when a model offers this hook."""
+        self._reset_amax_pool(input)
         return self._head_logits(self.backbone(input)), tuple(input.shape[2:])
 
     def forward(self, input, lbl=None):
+        self._reset_amax_pool(input)
         feats = self.backbone(input)
         logits = _up(self._head_logits(feats).contiguous(), input.shape[2:])  # NCHW logits for K2
         loss = None

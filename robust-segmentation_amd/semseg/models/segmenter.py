@@ -17,7 +17,9 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .convnext_upernet import StochasticDepth, _fp32_bwd, _fp32_fwd, _layer_norm, _linear_frozen, _up
+from . import convnext_upernet as _cu
+from .convnext_upernet import (StochasticDepth, _fp32_bwd, _fp32_fwd, _layer_norm, _linear_bound_word, _linear_frozen,
+                               _ln_bound_word, _up)
 
 
 def _init(m):
@@ -76,16 +78,21 @@ class Attention(nn.Module):
         self.proj = nn.Linear(dim, dim)
         self.proj_drop = nn.Dropout(dropout)
 
-    def forward(self, x):
+    def forward(self, x, amax=None):
         B, T, D = x.shape
-        # frozen weights (the attack's forward): M8 split-bf16 GEMMs, forward and input gradient; plain F.linear otherwise
+        # frozen weights (the attack's forward): M8 split GEMMs, forward and input gradient; plain F.linear otherwise.
+        # ``amax`` (fp16 x 2 mode): bound word of max|x| from the caller; the attention output is a convex combination of
+        # the v rows, so the analytic bound of |qkv| bounds the projection's input
         gc = self.__dict__.setdefault("_gemm_cache", ({}, {}))
-        qkv = _linear_frozen(gc[0], x, self.qkv.weight, self.qkv.bias)
+        a2 = None
+        if amax is not None and not (self.qkv.weight.requires_grad or self.qkv.bias.requires_grad):
+            a2 = _linear_bound_word(amax, self.qkv.weight, self.qkv.bias, gc[0])
+        qkv = _linear_frozen(gc[0], x, self.qkv.weight, self.qkv.bias, amax=amax)
         p = self.attn_drop.p if self.training else 0.0
         if (USE_HIP_ATTENTION and p == 0.0 and qkv.is_cuda and qkv.dtype == torch.float32 and D // self.heads == 64
                 and qkv.is_contiguous()):
             y = _AttentionHip.apply(qkv.view(B, T, 3, self.heads, 64), self.scale, self.qkv.weight.requires_grad)
-            return self.proj_drop(_linear_frozen(gc[1], y, self.proj.weight, self.proj.bias))
+            return self.proj_drop(_linear_frozen(gc[1], y, self.proj.weight, self.proj.bias, amax=a2))
         q, k, v = qkv.reshape(B, T, 3, self.heads, D // self.heads).permute(2, 0, 3, 1, 4)
         y = F.scaled_dot_product_attention(q, k, v, dropout_p=p, scale=self.scale)
         return self.proj_drop(self.proj(y.transpose(1, 2).reshape(B, T, D)))
@@ -99,10 +106,16 @@ class FeedForward(nn.Module):
         self.fc2 = nn.Linear(hidden, dim)
         self.drop = nn.Dropout(dropout)
 
-    def forward(self, x):
+    def forward(self, x, amax=None):
         gc = self.__dict__.setdefault("_gemm_cache", ({}, {}))
-        h = self.drop(self.act(_linear_frozen(gc[0], x, self.fc1.weight, self.fc1.bias)))
-        return self.drop(_linear_frozen(gc[1], h, self.fc2.weight, self.fc2.bias))
+        a2 = None
+        if amax is not None and not (self.fc1.weight.requires_grad or self.fc1.bias.requires_grad):
+            a2 = _linear_bound_word(amax, self.fc1.weight, self.fc1.bias, gc[0])   # |GELU(t)| <= |t| <= bound of the first GEMM
+        if ((not self.training or self.drop.p == 0.0) and self.act.approximate == "none"
+                and _cu._mlp_fusable(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)):
+            return _cu._FrozenMlp.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, None, gc, amax, a2)
+        h = self.drop(self.act(_linear_frozen(gc[0], x, self.fc1.weight, self.fc1.bias, amax=amax)))
+        return self.drop(_linear_frozen(gc[1], h, self.fc2.weight, self.fc2.bias, amax=a2))
 
 
 class Block(nn.Module):
@@ -114,9 +127,18 @@ class Block(nn.Module):
         self.mlp = FeedForward(dim, mlp_dim, dropout)
         self.drop_path = StochasticDepth(drop_path) if drop_path > 0.0 else nn.Identity()
 
+    def _bound(self, norm, x, slot):
+        """fp16 x 2 GEMMs after a frozen LayerNorm take the analytic bound of its output as activation scale (eval mode:
+        dropout would rescale the activations between the GEMMs)"""
+        from .. import _native as N
+        if (self.training or not x.is_cuda or _cu._terms() != 22 or not N.AMAX_FROM_PRODUCERS or norm.weight.requires_grad or norm.bias.requires_grad
+                or x.dtype != torch.float32):
+            return None
+        return _ln_bound_word(norm, self.__dict__.setdefault("_ln_cache", ({}, {}))[slot])
+
     def forward(self, x):
-        x = x + self.drop_path(self.attn(self.norm1(x)))
-        return x + self.drop_path(self.mlp(self.norm2(x)))
+        x = x + self.drop_path(self.attn(self.norm1(x), self._bound(self.norm1, x, 0)))
+        return x + self.drop_path(self.mlp(self.norm2(x), self._bound(self.norm2, x, 1)))
 
 
 class PatchEmbedding(nn.Module):
@@ -266,6 +288,7 @@ class SegMenter(nn.Module):
         H0, W0 = im.shape[2:]
         if H0 % self.patch_size or W0 % self.patch_size:
             return None
+        _cu.UperNetForSemanticSegmentation._reset_amax_pool(im)
         x = self.encoder(im, pre_neck=True)
         x = x[:, 0 if "SAM" in self.backbone else 1 + int(self.encoder.distilled):]
         return self.decoder(x, (H0, W0)).contiguous(), (H0, W0)
@@ -276,6 +299,7 @@ class SegMenter(nn.Module):
         if ph or pw:
             im = F.pad(im, (0, pw, 0, ph), value=0)
         H, W = im.shape[2:]
+        _cu.UperNetForSemanticSegmentation._reset_amax_pool(im)
         x = self.encoder(im, pre_neck=True)
         x = x[:, 0 if "SAM" in self.backbone else 1 + int(self.encoder.distilled):]
         masks = _up(self.decoder(x, (H, W)).contiguous(), (H, W))  # bilinear x16 (libsea_hip M2 on HIP tensors)

@@ -107,3 +107,169 @@ def test_fp16x2_handles_extreme_scales(N):
     out = N.gemm_split(A, N.gemm_split_pack(W, terms=22))
     for i in range(4):
         assert (out[i].double() - ref[i]).abs().max().item() <= 3e-6 * ref[i].abs().max().item()
+
+
+def test_fp16x2_activation_scale_from_the_producer(N):
+    """``amax`` = any upper bound of max|A| held in a device word (float bits) replaces the pass over A; ``out_amax``
+    receives the bits of max|out| for the next GEMM.  A loose bound must not cost accuracy (fp16 is floating point: only
+    the sub-normal range moves), a chained pair of GEMMs with GELU in between must match the explicit-pass result."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    A = torch.randn(3000, 96, generator=g, device="cuda") * 2.5
+    W1 = torch.randn(384, 96, generator=g, device="cuda") / 96 ** 0.5
+    W2 = torch.randn(96, 384, generator=g, device="cuda") / 384 ** 0.5
+    b1 = torch.randn(384, generator=g, device="cuda")
+    P1, P2 = N.gemm_split_pack(W1, terms=22), N.gemm_split_pack(W2, terms=22)
+    ref = _ref(A, W1, b1)
+    bits = lambda v: torch.tensor([v], dtype=torch.float32, device="cuda").view(torch.int32)
+    base = N.gemm_split(A, P1, bias=b1)
+    for slack in (1.0, 1.7, 37.0, 1000.0):
+        word = N.amax_word(A.device)
+        out = N.gemm_split(A, P1, bias=b1, amax=bits(A.abs().max().item() * slack), out_amax=word)
+        err = (out.double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err <= 2e-6, (slack, err)
+        assert word.view(torch.float32).item() == out.abs().max().item()          # exact: a max of the stored values
+        if slack == 1.0:
+            assert torch.equal(out, base)
+    h = torch.nn.functional.gelu(out)
+    assert h.abs().max().item() <= word.view(torch.float32).item()
+    y_chain = N.gemm_split(h, P2, amax=word)
+    y_pass = N.gemm_split(h, P2)
+    ref2 = _ref(h, W2)
+    for y in (y_chain, y_pass):
+        assert (y.double() - ref2).abs().max().item() <= 2e-6 * ref2.abs().max().item()
+    # the pool hands out zeroed words, and a reset zeroes the ones in use again
+    pool = N.AmaxPool.get(A.device)
+    pool.reset()
+    w = N.amax_word(A.device)
+    assert w.item() == 0
+    N.gemm_split(A, P1, amax=bits(20.0), out_amax=w)
+    assert w.item() != 0
+    pool.reset()
+    assert w.item() == 0
+
+
+@pytest.mark.parametrize("terms", [22, 3, 2])
+def test_fused_epilogue_addend_gelu_and_gelu_grad(N, terms):
+    """sea_gemm_split_fused: residual addend, second output GELU(C), factor GELU'(t) -- against the composed ATen ops on the
+    plain sea_gemm_split result (same products, same order: the GEMM part is bitwise the same)"""
+    import torch.nn.functional as F
+    g = torch.Generator(device="cuda").manual_seed(21)
+    M, K, Nn = 1000, 96, 384                                              # ragged M, N = 3 column blocks
+    A = torch.randn(M, K, generator=g, device="cuda") * 2
+    W = torch.randn(Nn, K, generator=g, device="cuda") / K ** 0.5
+    b = torch.randn(Nn, generator=g, device="cuda")
+    res = torch.randn(M, Nn, generator=g, device="cuda")
+    t = torch.randn(M, Nn, generator=g, device="cuda") * 2
+    P = N.gemm_split_pack(W, terms=terms)
+    base = N.gemm_split(A, P, bias=b)
+    # addend
+    out = N.gemm_split(A, P, bias=b, addend=res)
+    torch.testing.assert_close(out, base + res, rtol=0, atol=2e-6 * base.abs().max().item())
+    # addend read through a row stride (a column slice of a wider tensor)
+    wide = torch.randn(M, Nn + 32, generator=g, device="cuda")
+    out = N.gemm_split(A, P, bias=b, addend=wide[:, 16:16 + Nn])
+    torch.testing.assert_close(out, base + wide[:, 16:16 + Nn], rtol=0, atol=2e-6 * base.abs().max().item())
+    # dual output: C = pre-activation (bitwise the plain GEMM), gelu_out = GELU(C)
+    h = torch.empty_like(base)
+    word = N.amax_word(A.device) if terms == 22 else None
+    out = N.gemm_split(A, P, bias=b, gelu_out=h, out_amax=word)
+    assert torch.equal(out, base)
+    torch.testing.assert_close(h, F.gelu(base), rtol=1e-5, atol=1e-6)
+    if word is not None:
+        assert word.view(torch.float32).item() == base.abs().max().item()
+    # GELU' factor: the backward of y = GELU(t) applied to the GEMM result
+    out = N.gemm_split(A, P, gelu_grad_of=t)
+    tt = t.clone().requires_grad_(True)
+    (want,) = torch.autograd.grad(F.gelu(tt), tt, N.gemm_split(A, P))
+    torch.testing.assert_close(out, want, rtol=1e-5, atol=1e-6 * want.abs().max().item())
+    # batch of packed weights with all extras' batch strides
+    A3 = torch.randn(3, 260, 64, generator=g, device="cuda")
+    W3 = torch.randn(3, 130, 64, generator=g, device="cuda") / 8
+    r3 = torch.randn(3, 260, 130, generator=g, device="cuda")
+    P3 = N.gemm_split_pack(W3, terms=terms)
+    h3 = torch.empty(3, 260, 130, device="cuda")
+    o3 = N.gemm_split(A3, P3, addend=r3, gelu_out=h3)
+    b3 = N.gemm_split(A3, P3)
+    torch.testing.assert_close(o3, b3 + r3, rtol=0, atol=2e-6 * b3.abs().max().item())
+    torch.testing.assert_close(h3, F.gelu(o3), rtol=1e-5, atol=1e-6)
+    with pytest.raises(N.SeaNativeError):
+        N.gemm_split(A, P, gelu_out=h, gelu_grad_of=t)                    # one or the other
+    with pytest.raises(N.SeaNativeError):
+        N.gemm_split(A, P, addend=res[:, :-1])
+
+
+@pytest.mark.parametrize("terms", [22, 3, 2])
+def test_split_k_for_small_tile_grids(N, terms):
+    """few 128 x 128 tiles and a long K: the product runs as a batch of K slices + sea_gemm_splitk_reduce.  Same accuracy
+    as the single-pass product, bitwise reproducible, bias / ReLU / max|C| word in the reduce pass."""
+    g = torch.Generator(device="cuda").manual_seed(31)
+    for M, K, Nn, trans in ((2048, 3072, 768, False), (8192, 1536, 384, True), (2048, 4608, 512, True), (1300, 768, 132, False)):
+        A = torch.randn(M, K, generator=g, device="cuda")
+        W = torch.randn(Nn, K, generator=g, device="cuda") / K ** 0.5
+        b = torch.randn(Nn, generator=g, device="cuda")
+        S = N._ksplit(M, Nn, K)
+        assert S > 1 and K % (32 * S) == 0, (M, K, Nn, S)
+        P = N.gemm_split_pack(W.t().contiguous() if trans else W, trans=trans, terms=terms)
+        ref = _ref(A, W, b, relu=True)
+        word = N.amax_word(A.device) if terms == 22 else None
+        out = N.gemm_split(A, P, bias=b, relu=True, out_amax=word)
+        assert S in P.slices                                                   # the split path ran
+        N.KSPLIT = False
+        try:
+            one = N.gemm_split(A, P, bias=b, relu=True)
+        finally:
+            N.KSPLIT = True
+        scale = ref.abs().max().item()
+        e_split, e_one = (out.double() - ref).abs().max().item() / scale, (one.double() - ref).abs().max().item() / scale
+        print(f"M={M} K={K} N={Nn} terms {terms}: {S} K slices, max err / max|C| split {e_split:.2e}  single pass {e_one:.2e}")
+        assert e_split <= 1.5 * e_one + 2e-7
+        assert torch.equal(out, N.gemm_split(A, P, bias=b, relu=True))         # fixed summation order
+        if word is not None:
+            assert word.view(torch.float32).item() == out.abs().max().item()
+        # a row-strided output (column slice of a wider tensor)
+        wide = torch.zeros(M, Nn + 64, device="cuda")
+        N.gemm_split(A, P, bias=b, relu=True, out=wide[:, 32:32 + Nn])
+        assert torch.equal(wide[:, 32:32 + Nn], out) and not wide[:, :32].any() and not wide[:, 32 + Nn:].any()
+    assert N._ksplit(131072, 384, 96) == 1 and N._ksplit(2048, 768, 128) == 1 and N._ksplit(2048, 770, 3072) == 1
+
+
+def test_fp16x2_per_image_scales_make_rows_independent_of_their_batch(N):
+    """the activation scale is a power of two PER ROW, from the word of the row's group (image / Winograd tile): an
+    image's rows give the same bits whatever shares the batch with them.  (A per-tensor scale moves the sub-normal cut-off
+    of the low fp16 term: measured to break the sharded evaluation's bitwise 1-rank == 2-rank property.)"""
+    g = torch.Generator(device="cuda").manual_seed(17)
+    K, Nn, rows = 256, 192, 1536
+    W = torch.randn(Nn, K, generator=g, device="cuda") / K ** 0.5
+    P = N.gemm_split_pack(W, terms=22)
+    a0 = torch.randn(rows, K, generator=g, device="cuda") * torch.rand(rows, 1, generator=g, device="cuda") ** 8   # many tiny rows
+    alone = N.gemm_split(a0, P)
+    differ = 0
+    for partner_scale in (1.0, 37.0, 4096.0, 1e-3):
+        a1 = torch.randn(rows, K, generator=g, device="cuda") * partner_scale
+        pair = torch.cat([a0, a1])
+        out = N.gemm_split(pair, P, groups=2)                        # one exact word per image (sea_absmax_bits, rows_per_word)
+        assert torch.equal(out[:rows], alone), partner_scale
+        assert torch.equal(out[rows:], N.gemm_split(a1, P))
+        differ += int(not torch.equal(N.gemm_split(pair, P, groups=1)[:rows], alone))
+        # explicit words: per image, and per row (amax_rows = 1: what the Winograd transform supplies per tile)
+        w_img = torch.stack([a0.abs().max(), a1.abs().max()]).view(torch.int32)
+        assert torch.equal(N.gemm_split(pair, P, amax=w_img, amax_rows=rows), out)
+        w_row = pair.abs().amax(1).contiguous().view(torch.int32)
+        per_row = N.gemm_split(pair, P, amax=w_row, amax_rows=1)
+        assert torch.equal(per_row[:rows], N.gemm_split(a0, P, amax=w_row[:rows].contiguous(), amax_rows=1))
+        ref = _ref(pair, W)
+        assert (per_row.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    print(f"per-tensor scale changed image 0's bits for {differ} of 4 partners")
+    # the grouped maxima themselves, dense and row-strided, batch of matrices
+    A3 = torch.randn(3, 1000, 64, generator=g, device="cuda")
+    for rpw in (250, 128, 1):
+        words = torch.empty(-(-1000 // rpw), dtype=torch.int32, device="cuda")
+        N._check(N.lib().sea_absmax_bits(A3.data_ptr(), 64, 1000, 64, 3, 1000 * 64, rpw, words.data_ptr(), N._stream()), "absmax")
+        want = torch.stack([A3[:, i:i + rpw].abs().max() for i in range(0, 1000, rpw)])
+        assert torch.equal(words.view(torch.float32), want)
+    wide = torch.randn(1000, 96, generator=g, device="cuda")
+    words = torch.empty(4, dtype=torch.int32, device="cuda")
+    N._check(N.lib().sea_absmax_bits(wide[:, 16:].data_ptr(), 96, 1000, 64, 1, 0, 250, words.data_ptr(), N._stream()), "absmax")
+    assert torch.equal(words.view(torch.float32), torch.stack([wide[i:i + 250, 16:80].abs().max() for i in range(0, 1000, 250)]))
+    with pytest.raises(N.SeaNativeError):
+        N.gemm_split(a0, P, amax=w_img, amax_rows=1)                 # too few words

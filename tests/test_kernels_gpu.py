@@ -716,6 +716,32 @@ def test_winograd_conv3x3_forward_and_input_gradient(N, m, case):
         N.wino_conv3x3_cl(dev(x).contiguous() if W > 1 else dev(x)[:, :, :, :0], U, m)
 
 
+@pytest.mark.parametrize("terms", [22, 3, 2])
+def test_winograd_products_on_the_matrix_cores(N, terms):
+    """the Winograd-domain GEMMs through M8 (split operands): same result as the fp32 hipBLASLt batched GEMM to the
+    accuracy of the split; in fp16 x 2 mode the input transform itself supplies max|V| (no pass over V)"""
+    g = torch.Generator().manual_seed(5)
+    B, Cin, Cout, H, W = 2, 64, 96, 64, 60
+    x = (torch.randn(B, Cin, H, W, generator=g) * 3).cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)).cuda()
+    U = N.wino_filter(w, 4, False)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    y0 = N.wino_conv3x3_cl(x, U, 4)
+    y1 = N.wino_conv3x3_cl(x, U, 4, gemm_terms=terms)
+    e0 = (y0.double() - ref).abs().max().item() / ref.abs().max().item()
+    e1 = (y1.double() - ref).abs().max().item() / ref.abs().max().item()
+    print(f"winograd F(4,3), max err / max|y| vs float64 conv2d: fp32 GEMM {e0:.2e}, split terms {terms} {e1:.2e}")
+    # F(4x4,3x3) amplifies the rounding of its products ~20x (DESIGN.md): the yardstick is the fp32-GEMM Winograd path
+    assert e1 <= {22: 2.0, 3: 2.0, 2: 40.0}[terms] * e0 + 1e-6, (e0, e1)
+    # a list of inputs (virtual concatenation): every transform launch maxes into the same per-tile words
+    y2 = N.wino_conv3x3_cl([x[:, :32], x[:, 32:]], U, 4, gemm_terms=terms)
+    assert torch.equal(y1, y2)
+    # an image's result does not depend on its batch partner (fp16 x 2: per-tile scales; bf16 terms: no scales at all)
+    xb = torch.cat([x[:1], x[1:] * 300.0, x[1:] * 1e-3, x[:1]]).contiguous(memory_format=torch.channels_last)
+    yb = N.wino_conv3x3_cl(xb, U, 4, gemm_terms=terms)
+    assert torch.equal(yb[0], y1[0]) and torch.equal(yb[3], y1[0])
+
+
 def test_convmodule_winograd_matches_miopen(N):
     from semseg.models import convnext_upernet as M
     torch.manual_seed(1)
@@ -891,6 +917,49 @@ def test_convnext_block_frozen_weights_fold_layer_scale(N):
     fast2, ref2 = run(True), run(False)
     torch.testing.assert_close(fast2[0], ref2[0], rtol=2e-4, atol=2e-4 * ref2[0].abs().max().item())
     assert not torch.allclose(fast2[0], fast[0])
+
+
+@pytest.mark.parametrize("terms", [22, 3])
+def test_block_mlp_with_fused_epilogues_matches_the_unfused_pair(N, terms):
+    """_FrozenMlp (GELU / GELU' / residual in the GEMM epilogues) against the same two GEMMs with ATen's GELU and add
+    between them: same products, so only the element-wise rounding differs; ConvNeXt block and Segmenter feed-forward"""
+    from semseg.models import convnext_upernet as M
+    from semseg.models import segmenter as S
+    torch.manual_seed(4)
+    blk = M.Block(128).cuda().eval()
+    ff = S.FeedForward(192, 768, 0.0).cuda().eval()
+    with torch.no_grad():
+        blk.gamma.mul_(torch.rand(128, device="cuda") + 0.5)
+    for p in list(blk.parameters()) + list(ff.parameters()):
+        p.requires_grad_(False)
+    xb = torch.randn(2, 128, 24, 32, device="cuda").contiguous(memory_format=torch.channels_last)
+    xf = torch.randn(2, 600, 192, device="cuda")
+
+    def run(mod, x, fuse):
+        keep, M.FUSE_MLP = M.FUSE_MLP, 7 if fuse else 0
+        try:
+            with M._gemm_terms(terms):
+                xi = x.clone(memory_format=torch.preserve_format).requires_grad_(True)
+                y = mod(xi)
+                names = set()
+                stack = [y.grad_fn]
+                while stack:
+                    f = stack.pop()
+                    if f is not None:
+                        names.add(type(f).__name__)
+                        stack.extend(n for n, _ in f.next_functions)
+                (g,) = torch.autograd.grad((y * torch.cos(y)).sum(), xi)
+            return y.detach(), g, names
+        finally:
+            M.FUSE_MLP = keep
+
+    for mod, x in ((blk, xb), (ff, xf)):
+        y1, g1, n1 = run(mod, x, True)
+        y0, g0, n0 = run(mod, x, False)
+        assert "_FrozenMlpBackward" in n1 and "_FrozenMlpBackward" not in n0 and "GeluBackward0" in n0
+        torch.testing.assert_close(y1, y0, rtol=1e-5, atol=1e-5 * y0.abs().max().item())
+        torch.testing.assert_close(g1, g0, rtol=1e-4, atol=2e-5 * g0.abs().max().item())
+        assert y1.stride() == y0.stride()
 
 
 # ------------------------------------------------------------------------------------------------ full-size ADE workloads

@@ -403,6 +403,11 @@ typedef struct SeaGemmEpilogue {
   int64_t ld_addend, stride_addend;
   float* gelu_out;
   const float* gelu_grad_of;
+  const float* a_gelu_grad_of; /* PROLOGUE instead of epilogue (exclusive with the fields above; terms 2 or 22): A is read as
+                                * A * GELU'(a_gelu_grad_of), same layout as A (lda, strideA): the GELU backward in front of the
+                                * first projection's input-gradient GEMM, applied while the tile is staged */
+  int a_gelu;                  /* PROLOGUE (exclusive with everything above): A is read as GELU(A): the activation in front of the
+                                * second projection's forward GEMM, without materialising GELU(A) */
 } SeaGemmEpilogue;
 int sea_gemm_split_fused(const float* A, int64_t lda, const void* Wp, float* C, int64_t ldc, const float* bias, int relu, int M,
                          int N, int K, int terms, int batch, int64_t strideA, int64_t strideW_bytes, int64_t strideC,

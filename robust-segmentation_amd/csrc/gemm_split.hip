@@ -118,6 +118,8 @@ struct GemmSplitArgs {
   int64_t ld_add, stride_add;
   float* gelu_out;             // layout of C: receives GELU(C); C keeps the pre-activation
   const float* gelu_grad_of;   // layout of C: the result is multiplied by GELU'(this)
+  const float* a_gelu_grad_of; // layout of A: A is read as A * GELU'(this) (the backward of a GELU in front of the GEMM)
+  int a_gelu;                  // A is read as GELU(A) (the GELU in front of the GEMM)
 };
 
 // exact (erf) GELU and its derivative, the formulas of ATen's GeluCUDAKernelImpl / GeluBackwardCUDAKernelImpl
@@ -128,8 +130,9 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return cdf + x * pdf;
 }
 
-// EPI: the fused epilogue extras (addend / gelu_out / gelu_grad_of) are compiled in
-template <int TERMS, bool S16, bool F16 = false, bool EPI = false>
+// EPI: the fused epilogue extras (addend / gelu_out / gelu_grad_of) are compiled in; PRO: the prologue factor GELU'(.) on A
+// (PRO = 1: A * GELU'(second operand); PRO = 2: GELU(A))
+template <int TERMS, bool S16, bool F16 = false, bool EPI = false, int PRO = 0>
 __global__ __launch_bounds__(256, 3) void gemm_split_kernel(const GemmSplitArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * TERMS * GS_IMG];
   char* As = smem;
@@ -197,11 +200,18 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(const GemmSplitArgs 
   const uint32_t woff = (uint32_t)tid * 16;
 
   f32x4 pa[4];
+  f32x4 pt[PRO == 1 ? 4 : 1];
+  const char* const Tbase = PRO == 1 ? (const char*)(p.a_gelu_grad_of + (int64_t)g * p.strideA) : nullptr;
   u32x4 pw[2 * TERMS];
   auto fetch = [&](int kb) {
     const char* a = Abase + (int64_t)kb * (GS_BK * 4);
 #pragma unroll
     for (int i = 0; i < 4; ++i) pa[i] = *(const f32x4*)(a + aoff[i]);
+    if constexpr (PRO == 1) {
+      const char* t = Tbase + (int64_t)kb * (GS_BK * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pt[i] = *(const f32x4*)(t + aoff[i]);
+    }
     const char* w = Wbase + (int64_t)kb * w_kb;
 #pragma unroll
     for (int i = 0; i < 2 * TERMS; ++i) pw[i] = *(const u32x4*)(w + (int64_t)(i >> 1) * w_term + (i & 1) * 4096 + woff);
@@ -210,6 +220,14 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(const GemmSplitArgs 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       u32x2 s[TERMS];
+      if constexpr (PRO == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pa[i][e] *= gelu_grad_f(pt[i][e]);
+      }
+      if constexpr (PRO == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pa[i][e] = gelu_f(pa[i][e]);
+      }
       if constexpr (F16)
         split4_f16(pa[i], a_sc[i], s);
       else
@@ -663,6 +681,8 @@ extern "C" int sea_gemm_split_fused(const float* A, int64_t lda, const void* Wp,
   if (epi) {
     SEA_CHECK_ARG(!epi->addend || epi->ld_addend >= N);
     SEA_CHECK_ARG(!(epi->gelu_out && epi->gelu_grad_of) && !(relu && (epi->gelu_out || epi->gelu_grad_of)));
+    SEA_CHECK_ARG(!(epi->a_gelu_grad_of || epi->a_gelu) || !(epi->addend || epi->gelu_out || epi->gelu_grad_of));
+    SEA_CHECK_ARG(!(epi->a_gelu_grad_of && epi->a_gelu));
   }
   return gemm_split_impl(A, lda, Wp, C, ldc, bias, relu, M, N, K, terms, batch, strideA, strideW_bytes, strideC,
                          terms == 22 ? amax_bits : nullptr, amax_rows, out_amax, stream, epi);
@@ -740,6 +760,8 @@ static int gemm_split_impl(const float* A, int64_t lda, const void* Wp, float* C
   p.stride_add = epi ? epi->stride_addend : 0;
   p.gelu_out = epi ? epi->gelu_out : nullptr;
   p.gelu_grad_of = epi ? epi->gelu_grad_of : nullptr;
+  p.a_gelu_grad_of = epi ? epi->a_gelu_grad_of : nullptr;
+  p.a_gelu = epi ? epi->a_gelu : 0;
   p.w_inv = terms == 22 ? (const float*)((const char*)Wp + (int64_t)(K / GS_BK) * 2 * gs_npad(N) * GS_BK * 2) : nullptr;
   const dim3 grid(p.per_xcd * 8), block(256);
   // MFMA shape: v_mfma_f32_32x32x16_bf16 fragments (default); SEA_GEMM_SHAPE=16 selects v_mfma_f32_16x16x32_bf16
@@ -749,6 +771,24 @@ static int gemm_split_impl(const float* A, int64_t lda, const void* Wp, float* C
     return (e && e[0] == '1') ? 1 : 0;
   }();
   const bool fused = p.addend || p.gelu_out || p.gelu_grad_of;   // (32 x 32 fragments only)
+  if (p.a_gelu) {   // A := GELU(A) while the tile is staged (forward of the second projection)
+    SEA_CHECK_ARG(!fused && !p.a_gelu_grad_of && (terms == 2 || terms == 3 || terms == 22));
+    if (terms == 22)
+      hipLaunchKernelGGL((gemm_split_kernel<2, false, true, false, 2>), grid, block, 0, (hipStream_t)stream, p);
+    else if (terms == 3)
+      hipLaunchKernelGGL((gemm_split_kernel<3, false, false, false, 2>), grid, block, 0, (hipStream_t)stream, p);
+    else
+      hipLaunchKernelGGL((gemm_split_kernel<2, false, false, false, 2>), grid, block, 0, (hipStream_t)stream, p);
+    SEA_RETURN_LAST();
+  }
+  if (p.a_gelu_grad_of) {   // prologue variant: two bf16 terms (the input-gradient mode) or fp16 x 2
+    SEA_CHECK_ARG(!fused && (terms == 2 || terms == 22) && (((uintptr_t)p.a_gelu_grad_of) & 15) == 0);
+    if (terms == 22)
+      hipLaunchKernelGGL((gemm_split_kernel<2, false, true, false, 1>), grid, block, 0, (hipStream_t)stream, p);
+    else
+      hipLaunchKernelGGL((gemm_split_kernel<2, false, false, false, 1>), grid, block, 0, (hipStream_t)stream, p);
+    SEA_RETURN_LAST();
+  }
   if (terms == 22) {
     if (fused)
       hipLaunchKernelGGL((gemm_split_kernel<2, false, true, true>), grid, block, 0, (hipStream_t)stream, p);

@@ -792,7 +792,7 @@ def _ksplit_workspace(device, numel):
 
 class _GemmEpilogue(C.Structure):       # SeaGemmEpilogue of include/sea_hip.h
     _fields_ = [("addend", C.c_void_p), ("ld_addend", C.c_int64), ("stride_addend", C.c_int64),
-                ("gelu_out", C.c_void_p), ("gelu_grad_of", C.c_void_p)]
+                ("gelu_out", C.c_void_p), ("gelu_grad_of", C.c_void_p), ("a_gelu_grad_of", C.c_void_p), ("a_gelu", C.c_int)]
 
 
 def _amax_words(A3, M, K, G, sA, groups):
@@ -804,7 +804,8 @@ def _amax_words(A3, M, K, G, sA, groups):
 
 
 def gemm_split(A, Wp: PackedWeight, bias=None, relu: bool = False, out=None, amax=None, out_amax=None, addend=None,
-               gelu_out=None, gelu_grad_of=None, amax_rows: int = 0, groups: int = 1):
+               gelu_out=None, gelu_grad_of=None, amax_rows: int = 0, groups: int = 1, a_gelu_grad_of=None,
+               a_gelu: bool = False):
     """out (.., N) = A (.., K) @ W^T [+ bias] [ReLU] with W pre-split (``gemm_split_pack``).  A: fp32, last dim
     contiguous; 2-D (M, K) with any 4-aligned row stride, or (G, M, K) against a batch of G packed weights.
     fp16 x 2 weights (terms 22): ``amax`` = device words holding the float bits of (upper bounds of) max|A|, one per
@@ -813,8 +814,9 @@ def gemm_split(A, Wp: PackedWeight, bias=None, relu: bool = False, out=None, ama
     receives the bits of max|out|.
     Fused epilogue (sea_gemm_split_fused): ``addend`` (shape of out, last dim contiguous) is added before the activation;
     ``gelu_out`` (layout of out) receives GELU(out) while out keeps the pre-activation; the result is multiplied by
-    GELU'(``gelu_grad_of``) (layout of out)."""
-    _dev(A, bias, out, addend, gelu_out, gelu_grad_of)
+    GELU'(``gelu_grad_of``) (layout of out).  Prologue instead (exclusive): A is read as A * GELU'(``a_gelu_grad_of``)
+    (same shape and strides as A; terms 2 or 22), or as GELU(A) (``a_gelu``)."""
+    _dev(A, bias, out, addend, gelu_out, gelu_grad_of, a_gelu_grad_of)
     batched = Wp.batch > 1 or A.dim() == 3
     A3 = A if A.dim() == 3 else A.unsqueeze(0)
     if (A.dtype != torch.float32 or A3.dim() != 3 or A3.shape[0] != Wp.batch or A3.shape[2] != Wp.K
@@ -832,15 +834,22 @@ def gemm_split(A, Wp: PackedWeight, bias=None, relu: bool = False, out=None, ama
     if amax is not None and (amax.dtype != torch.int32 or not amax.is_contiguous()
                              or amax.numel() < (-(-M // amax_rows) if amax_rows > 0 else 1)):
         raise SeaNativeError("gemm_split: amax must hold one int32 word per amax_rows rows")
-    fused = addend is not None or gelu_out is not None or gelu_grad_of is not None
-    if G == 1 and not fused and Wp.src is not None and O3.stride(1) % 4 == 0 and O3.data_ptr() % 16 == 0:
+    fused = (addend is not None or gelu_out is not None or gelu_grad_of is not None or a_gelu_grad_of is not None
+             or a_gelu)
+    if a_gelu_grad_of is not None and (a_gelu_grad_of.shape != A.shape or a_gelu_grad_of.stride() != A.stride()
+                                       or a_gelu_grad_of.dtype != torch.float32 or Wp.terms not in (2, 22)):
+        raise SeaNativeError("gemm_split: a_gelu_grad_of must be float32 with A's shape and strides (terms 2 or 22)")
+    only_pro = (a_gelu_grad_of is not None or a_gelu) and addend is None and gelu_out is None and gelu_grad_of is None
+    if G == 1 and (not fused or only_pro) and Wp.src is not None and O3.stride(1) % 4 == 0 and O3.data_ptr() % 16 == 0:
         S = _ksplit(M, Wp.N, K)
         if S > 1:
             if Wp.terms == 22 and amax is None:
                 amax, amax_rows = _amax_words(A3, M, K, 1, 0, groups)
             part = _ksplit_workspace(A.device, S * M * Wp.N).view(S, M, Wp.N)
-            gemm_split(A3[0].as_strided((S, M, K // S), (K // S, A3.stride(1), 1)), Wp.k_slices(S), out=part, amax=amax,
-                       amax_rows=amax_rows)
+            shape, strides = (S, M, K // S), (K // S, A3.stride(1), 1)
+            gemm_split(A3[0].as_strided(shape, strides), Wp.k_slices(S), out=part, amax=amax, amax_rows=amax_rows,
+                       a_gelu_grad_of=None if a_gelu_grad_of is None else a_gelu_grad_of.as_strided(shape, strides),
+                       a_gelu=a_gelu)
             _check(lib().sea_gemm_splitk_reduce(_p(part), S, M, Wp.N, _p(bias), int(relu), _p(O3), O3.stride(1),
                                                 _p(out_amax) if Wp.terms == 22 else None, _stream()), "sea_gemm_splitk_reduce")
             return out
@@ -857,6 +866,9 @@ def gemm_split(A, Wp: PackedWeight, bias=None, relu: bool = False, out=None, ama
                 if T3.shape != O3.shape or T3.stride() != O3.stride() or t.dtype != torch.float32:
                     raise SeaNativeError(f"gemm_split: {name} must be float32 with the output's shape and strides")
                 setattr(epi, name, T3.data_ptr())
+        if a_gelu_grad_of is not None:
+            epi.a_gelu_grad_of = a_gelu_grad_of.data_ptr()
+        epi.a_gelu = int(bool(a_gelu))
         if Wp.terms == 22 and amax is None:
             amax, amax_rows = _amax_words(A3, M, K, G, sA, groups)
         _check(lib().sea_gemm_split_fused(_p(A3), A3.stride(1), _p(Wp.data), _p(O3), O3.stride(1), _p(bias), int(relu), M, Wp.N,

@@ -363,19 +363,25 @@ def _linear_frozen(mod_cache, x, w, b, amax=None, out_amax=None):
     return F.linear(x, w, b)
 
 
-# Element-wise neighbours of a block's MLP in the GEMM epilogues (sea_gemm_split_fused).  Bit mask: 1 = GELU in the first
-# forward GEMM's epilogue, 2 = GELU' in the first backward GEMM's, 4 = residual add in the second forward GEMM's.
-# MEASURED SLOWER on MI355X and therefore OFF by default (UperNet-ConvNeXt-T, B=8, 512x512, ms per APGD step:
-# 0: 18.16, 1: 18.24, 4: 18.59, 2: 18.97, 7: 19.32): the separate ATen passes stream from the 256 MiB Infinity Cache
-# at full occupancy, while the same loads / erf evaluations in the epilogue of a short-K GEMM run at 3 waves per SIMD
-# behind the accumulators (64 scalar accesses per lane).  Kept as a tested option of the C ABI.
-FUSE_MLP = int(os.environ.get("SEA_FUSE_MLP", "0"))
+# Element-wise neighbours of a block's MLP inside its GEMMs (sea_gemm_split_fused).  Bit mask (env SEA_FUSE_MLP; -1 = the
+# two projections as separate autograd nodes with ATen's GELU between them):
+#   8 = GELU' applied to the A tile of the first projection's input-gradient GEMM while it is staged (prologue): removes
+#       the GELU-backward pass and one write + read of the 4C-wide gradient.  Used where that GEMM has at most
+#       FUSE_PROLOGUE_MAX_NBLOCKS column blocks (every column block re-stages A and would re-evaluate erf).  DEFAULT.
+#   1 = GELU in the first forward GEMM's epilogue, 2 = GELU' in the second backward GEMM's epilogue, 4 = residual add in
+#       the second forward GEMM's epilogue: MEASURED SLOWER on MI355X and off (UperNet-ConvNeXt-T, B=8, 512x512, ms per
+#       APGD step: none 18.16, 1: 18.24, 4: 18.59, 2: 18.97, 7: 19.32): the separate ATen passes stream from the 256 MiB
+#       Infinity Cache at full occupancy, while the same loads / erf evaluations in the epilogue of a short-K GEMM run at 3
+#       waves per SIMD behind the accumulators (64 scalar accesses per lane).  Kept as tested options of the C ABI.
+#  16 = GELU applied to the A tile of the second projection's forward GEMM while it is staged: GELU(t) is never written.
+FUSE_MLP = int(os.environ.get("SEA_FUSE_MLP", "24"))
+FUSE_PROLOGUE_MAX_NBLOCKS = int(os.environ.get("SEA_FUSE_PRO_NB", "3"))
 
 
 def _mlp_fusable(x, w1, b1, w2, b2):
     """both projections of a block's MLP qualify for M8 (frozen weights, fp32 HIP tensor, shapes): the pair runs as two
     GEMMs with GELU, GELU' and the residual add in their epilogues (_FrozenMlp)"""
-    return (FUSE_MLP and _terms() in (2, 3, 22) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+    return (FUSE_MLP >= 0 and _terms() in (2, 3, 22) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
             and not torch.is_autocast_enabled() and x.numel() // x.shape[-1] >= GEMM_MIN_ROWS
             and w1.shape[1] % 32 == 0 and w2.shape[1] % 32 == 0 and w2.shape[0] == x.shape[-1]
             and not any(t is not None and t.requires_grad for t in (w1, b1, w2, b2)))
@@ -399,15 +405,22 @@ class _FrozenMlp(torch.autograd.Function):
         t = torch.empty(x2.shape[0], w1.shape[0], dtype=torch.float32, device=x.device)
         fuse, nb = int(FUSE_MLP), (x.shape[0] if x.dim() > 2 else 1)
         r2 = None if res is None else res.reshape(-1, res.shape[-1])
-        if fuse & 1:
+        pro = bool(fuse & 16) and -(-w2.shape[0] // 128) <= FUSE_PROLOGUE_MAX_NBLOCKS and not fuse & 1
+        if pro:
+            N.gemm_split(x2, _packed(w1, caches[0], "lin_fwd", False, terms), bias=b1, out=t, amax=a1, groups=nb)
+            h = t
+        elif fuse & 1:
             h = torch.empty_like(t)
             N.gemm_split(x2, _packed(w1, caches[0], "lin_fwd", False, terms), bias=b1, out=t, gelu_out=h, amax=a1, groups=nb)
         else:
             N.gemm_split(x2, _packed(w1, caches[0], "lin_fwd", False, terms), bias=b1, out=t, amax=a1, groups=nb)
             h = F.gelu(t)
-        y = N.gemm_split(h, _packed(w2, caches[1], "lin_fwd", False, terms), bias=b2, amax=a2, addend=r2 if fuse & 4 else None,
-                         groups=nb)
-        if r2 is not None and not fuse & 4:
+        if pro:
+            y = N.gemm_split(t, _packed(w2, caches[1], "lin_fwd", False, terms), bias=b2, amax=a2, groups=nb, a_gelu=True)
+        else:
+            y = N.gemm_split(h, _packed(w2, caches[1], "lin_fwd", False, terms), bias=b2, amax=a2,
+                             addend=r2 if fuse & 4 else None, groups=nb)
+        if r2 is not None and (pro or not fuse & 4):
             y += r2
         ctx.fuse = fuse
         ctx.save_for_backward(t)
@@ -423,11 +436,14 @@ class _FrozenMlp(torch.autograd.Function):
         g2 = g.reshape(-1, g.shape[-1])
         if not g2.is_contiguous():
             g2 = g2.contiguous()
+        nb = ctx.shape[0] if len(ctx.shape) > 2 else 1
+        p2, p1 = (_packed(ctx.w[1], ctx.caches[1], "lin_bwd", True, terms), _packed(ctx.w[0], ctx.caches[0], "lin_bwd", True, terms))
         if ctx.fuse & 2:
-            gh = N.gemm_split(g2, _packed(ctx.w[1], ctx.caches[1], "lin_bwd", True, terms), gelu_grad_of=t)
+            gx = N.gemm_split(N.gemm_split(g2, p2, gelu_grad_of=t, groups=nb), p1, groups=nb)
+        elif ctx.fuse & 8 and terms in (2, 22) and -(-ctx.w[0].shape[1] // 128) <= FUSE_PROLOGUE_MAX_NBLOCKS:
+            gx = N.gemm_split(N.gemm_split(g2, p2, groups=nb), p1, a_gelu_grad_of=t, groups=nb)
         else:
-            gh = torch.ops.aten.gelu_backward(N.gemm_split(g2, _packed(ctx.w[1], ctx.caches[1], "lin_bwd", True, terms)), t)
-        gx = N.gemm_split(gh, _packed(ctx.w[0], ctx.caches[0], "lin_bwd", True, terms))
+            gx = N.gemm_split(torch.ops.aten.gelu_backward(N.gemm_split(g2, p2, groups=nb), t), p1, groups=nb)
         return gx.view(ctx.shape), None, None, None, None, (g if ctx.has_res else None), None, None, None
 
 

@@ -192,6 +192,28 @@ def test_fused_epilogue_addend_gelu_and_gelu_grad(N, terms):
     b3 = N.gemm_split(A3, P3)
     torch.testing.assert_close(o3, b3 + r3, rtol=0, atol=2e-6 * b3.abs().max().item())
     torch.testing.assert_close(h3, F.gelu(o3), rtol=1e-5, atol=1e-6)
+    # prologue: A read as GELU(A) while it is staged
+    got = N.gemm_split(A, P, bias=b, a_gelu=True)
+    plain = N.gemm_split(F.gelu(A), P, bias=b)
+    want = _ref(F.gelu(A.double()).float(), W, b)
+    e_got, e_plain = ((got.double() - want).abs().max().item(), (plain.double() - want).abs().max().item())
+    assert e_got <= 1.5 * e_plain + 2e-6 * want.abs().max().item(), (e_got, e_plain)
+    # prologue: A read as A * GELU'(s) while it is staged (terms 2 / 22)
+    if terms in (2, 22):
+        sA = torch.randn(M, K, generator=g, device="cuda") * 2
+        ss = sA.clone().requires_grad_(True)
+        (Ag,) = torch.autograd.grad(F.gelu(ss), ss, A)
+        want = _ref(Ag, W)
+        got = N.gemm_split(A, P, a_gelu_grad_of=sA)
+        plain = N.gemm_split(Ag, P)
+        e_got, e_plain = ((got.double() - want).abs().max().item(), (plain.double() - want).abs().max().item())
+        assert e_got <= 1.5 * e_plain + 2e-6 * want.abs().max().item(), (e_got, e_plain)
+        wideA, wideS = torch.zeros(M, K + 32, device="cuda"), torch.zeros(M, K + 32, device="cuda")
+        wideA[:, 16:16 + K], wideS[:, 16:16 + K] = A, sA
+        assert torch.equal(N.gemm_split(wideA[:, 16:16 + K], P, a_gelu_grad_of=wideS[:, 16:16 + K]), got)
+    else:
+        with pytest.raises(N.SeaNativeError):
+            N.gemm_split(A, P, a_gelu_grad_of=A)
     with pytest.raises(N.SeaNativeError):
         N.gemm_split(A, P, gelu_out=h, gelu_grad_of=t)                    # one or the other
     with pytest.raises(N.SeaNativeError):

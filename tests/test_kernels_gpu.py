@@ -936,7 +936,7 @@ def test_block_mlp_with_fused_epilogues_matches_the_unfused_pair(N, terms):
     xf = torch.randn(2, 600, 192, device="cuda")
 
     def run(mod, x, fuse):
-        keep, M.FUSE_MLP = M.FUSE_MLP, 7 if fuse else 0
+        keep, M.FUSE_MLP = M.FUSE_MLP, fuse
         try:
             with M._gemm_terms(terms):
                 xi = x.clone(memory_format=torch.preserve_format).requires_grad_(True)
@@ -954,12 +954,16 @@ def test_block_mlp_with_fused_epilogues_matches_the_unfused_pair(N, terms):
             M.FUSE_MLP = keep
 
     for mod, x in ((blk, xb), (ff, xf)):
-        y1, g1, n1 = run(mod, x, True)
-        y0, g0, n0 = run(mod, x, False)
-        assert "_FrozenMlpBackward" in n1 and "_FrozenMlpBackward" not in n0 and "GeluBackward0" in n0
-        torch.testing.assert_close(y1, y0, rtol=1e-5, atol=1e-5 * y0.abs().max().item())
-        torch.testing.assert_close(g1, g0, rtol=1e-4, atol=2e-5 * g0.abs().max().item())
-        assert y1.stride() == y0.stride()
+        y0, g0, n0 = run(mod, x, -1)                       # separate autograd nodes, ATen GELU
+        assert "_FrozenMlpBackward" not in n0 and "GeluBackward0" in n0
+        for mask in (7, 24, 8, 0):                         # epilogue fusions / the default prologues (GELU, GELU') / none
+            y1, g1, n1 = run(mod, x, mask)
+            assert "_FrozenMlpBackward" in n1 and "GeluBackward0" not in n1
+            torch.testing.assert_close(y1, y0, rtol=1e-5, atol=1e-5 * y0.abs().max().item())
+            torch.testing.assert_close(g1, g0, rtol=1e-4, atol=2e-5 * g0.abs().max().item())
+            assert y1.stride() == y0.stride()
+        if mask == 0:
+            assert torch.equal(y1, y0)
 
 
 # ------------------------------------------------------------------------------------------------ full-size ADE workloads

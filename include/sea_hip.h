@@ -389,8 +389,8 @@ int sea_gemm_split_pack(const float* W, int64_t ldw, int trans, int N, int K, in
  * `splits` GEMMs over K slices (batch strides of sea_gemm_split: A + s K/splits, packed slices of W) into a dense
  * (splits, M, N) workspace; this kernel adds the slices in the fixed order 0, 1, .. (bitwise reproducible), then bias,
  * ReLU and the optional max|C| word.  N % 4 == 0, ldc % 4 == 0, 16-byte aligned pointers. */
-int sea_gemm_splitk_reduce(const float* partial, int splits, int M, int N, const float* bias, int relu, float* C, int64_t ldc,
-                           uint32_t* out_amax, void* stream);
+int sea_gemm_splitk_reduce(const float* partial, int splits, int M, int N, const float* bias, const float* addend,
+                           int64_t ld_addend, int relu, float* C, int64_t ldc, uint32_t* out_amax, void* stream);
 /* sea_gemm_split_fused: the same GEMM (terms 2 / 3 / 22; amax_bits / out_amax as above, 22 only) with the element-wise
  * neighbours of the MLP of a ConvNeXt / ViT block (convnext_orig.py:38-58, vit_encoder.py:41-60) in its epilogue:
  *   v = A W^T + bias + addend;  relu;  v *= GELU'(gelu_grad_of);  C = v;  gelu_out = GELU(v)     (exact erf GELU)

@@ -577,7 +577,8 @@ __global__ void zero_words_kernel(uint32_t* __restrict__ p, int n) {
 // C[m][n] = act(sum_s partial[s][m][n] + bias[n]) in the fixed order s = 0, 1, ..: the second pass of a split-K product
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const f32x4* __restrict__ part, int S, int64_t per_split4, int M,
                                                             int N4, const f32x4* __restrict__ bias, int relu,
-                                                            float* __restrict__ C, int64_t ldc, uint32_t* __restrict__ out_amax) {
+                                                            float* __restrict__ C, int64_t ldc, uint32_t* __restrict__ out_amax,
+                                                            const float* __restrict__ addend, int64_t ld_add) {
   const int64_t total = (int64_t)M * N4;
   uint32_t omax = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -586,6 +587,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const f32x4* __restr
     f32x4 v = part[i];
     for (int sidx = 1; sidx < S; ++sidx) v += part[sidx * per_split4 + i];
     if (bias) v += bias[c4];
+    if (addend) v += *(const f32x4*)(addend + row * ld_add + 4 * c4);
     if (relu) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
@@ -689,13 +691,14 @@ extern "C" int sea_gemm_split_fused(const float* A, int64_t lda, const void* Wp,
 }
 
 // split-K second pass: C (M x N, row stride ldc) = act(sum over `splits` partial products (each M x N, dense) + bias)
-extern "C" int sea_gemm_splitk_reduce(const float* partial, int splits, int M, int N, const float* bias, int relu, float* C,
-                                      int64_t ldc, uint32_t* out_amax, void* stream) {
+extern "C" int sea_gemm_splitk_reduce(const float* partial, int splits, int M, int N, const float* bias, const float* addend,
+                                      int64_t ld_addend, int relu, float* C, int64_t ldc, uint32_t* out_amax, void* stream) {
   SEA_CHECK_ARG(partial && C && splits >= 1 && M > 0 && N > 0 && (N % 4) == 0 && ldc >= N && (ldc % 4) == 0);
-  SEA_CHECK_ARG(((((uintptr_t)partial) | ((uintptr_t)C) | ((uintptr_t)bias)) & 15) == 0);
+  SEA_CHECK_ARG(((((uintptr_t)partial) | ((uintptr_t)C) | ((uintptr_t)bias) | ((uintptr_t)addend)) & 15) == 0);
+  SEA_CHECK_ARG(!addend || (ld_addend >= N && (ld_addend % 4) == 0));
   const int64_t total = (int64_t)M * (N / 4);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)partial,
-                     splits, total, M, N / 4, (const f32x4*)bias, relu, C, ldc, out_amax);
+                     splits, total, M, N / 4, (const f32x4*)bias, relu, C, ldc, out_amax, addend, ld_addend);
   SEA_RETURN_LAST();
 }
 

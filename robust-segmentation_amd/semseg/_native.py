@@ -76,7 +76,7 @@ _SIGS = {
     "sea_gemm_split_f16": (_i, [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _i, _i64, _i64, _i64, _vp, _i, _vp, _vp]),
     "sea_wino_input_transform_amax": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp]),
     "sea_gemm_split_fused": (_i, [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _vp, _i, _vp, _vp, _vp]),
-    "sea_gemm_splitk_reduce": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i64, _vp, _vp]),
+    "sea_gemm_splitk_reduce": (_i, [_vp, _i, _i, _i, _vp, _vp, _i64, _i, _vp, _i64, _vp, _vp]),
     "sea_gemm_split_packed_bytes": (_i64, [_i, _i, _i]),
     "sea_gemm_split_pack": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp]),
     "sea_gemm_split": (_i, [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _vp]),
@@ -839,8 +839,11 @@ def gemm_split(A, Wp: PackedWeight, bias=None, relu: bool = False, out=None, ama
     if a_gelu_grad_of is not None and (a_gelu_grad_of.shape != A.shape or a_gelu_grad_of.stride() != A.stride()
                                        or a_gelu_grad_of.dtype != torch.float32 or Wp.terms not in (2, 22)):
         raise SeaNativeError("gemm_split: a_gelu_grad_of must be float32 with A's shape and strides (terms 2 or 22)")
-    only_pro = (a_gelu_grad_of is not None or a_gelu) and addend is None and gelu_out is None and gelu_grad_of is None
-    if G == 1 and (not fused or only_pro) and Wp.src is not None and O3.stride(1) % 4 == 0 and O3.data_ptr() % 16 == 0:
+    # split-K takes the prologues (applied per slice) and the addend (added by the reduce pass)
+    only_pro = gelu_out is None and gelu_grad_of is None
+    add_ok = addend is None or (addend.dim() == 2 and addend.shape == O3.shape[1:] and addend.stride(1) == 1
+                                and addend.stride(0) % 4 == 0 and addend.data_ptr() % 16 == 0 and addend.dtype == torch.float32)
+    if G == 1 and (not fused or (only_pro and add_ok)) and Wp.src is not None and O3.stride(1) % 4 == 0 and O3.data_ptr() % 16 == 0:
         S = _ksplit(M, Wp.N, K)
         if S > 1:
             if Wp.terms == 22 and amax is None:
@@ -850,7 +853,8 @@ def gemm_split(A, Wp: PackedWeight, bias=None, relu: bool = False, out=None, ama
             gemm_split(A3[0].as_strided(shape, strides), Wp.k_slices(S), out=part, amax=amax, amax_rows=amax_rows,
                        a_gelu_grad_of=None if a_gelu_grad_of is None else a_gelu_grad_of.as_strided(shape, strides),
                        a_gelu=a_gelu)
-            _check(lib().sea_gemm_splitk_reduce(_p(part), S, M, Wp.N, _p(bias), int(relu), _p(O3), O3.stride(1),
+            _check(lib().sea_gemm_splitk_reduce(_p(part), S, M, Wp.N, _p(bias), _p(addend),
+                                                addend.stride(0) if addend is not None else 0, int(relu), _p(O3), O3.stride(1),
                                                 _p(out_amax) if Wp.terms == 22 else None, _stream()), "sea_gemm_splitk_reduce")
             return out
     if fused:

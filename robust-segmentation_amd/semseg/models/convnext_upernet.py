@@ -375,6 +375,7 @@ def _linear_frozen(mod_cache, x, w, b, amax=None, out_amax=None):
 #       waves per SIMD behind the accumulators (64 scalar accesses per lane).  Kept as tested options of the C ABI.
 #  16 = GELU applied to the A tile of the second projection's forward GEMM while it is staged: GELU(t) is never written.
 FUSE_MLP = int(os.environ.get("SEA_FUSE_MLP", "24"))
+REDUCE_ADD = os.environ.get("SEA_REDUCE_ADD", "1") != "0"   # A/B: the residual in the split-K reduce pass
 FUSE_PROLOGUE_MAX_NBLOCKS = int(os.environ.get("SEA_FUSE_PRO_NB", "3"))
 
 
@@ -415,12 +416,13 @@ class _FrozenMlp(torch.autograd.Function):
         else:
             N.gemm_split(x2, _packed(w1, caches[0], "lin_fwd", False, terms), bias=b1, out=t, amax=a1, groups=nb)
             h = F.gelu(t)
-        if pro:
-            y = N.gemm_split(t, _packed(w2, caches[1], "lin_fwd", False, terms), bias=b2, amax=a2, groups=nb, a_gelu=True)
-        else:
-            y = N.gemm_split(h, _packed(w2, caches[1], "lin_fwd", False, terms), bias=b2, amax=a2,
-                             addend=r2 if fuse & 4 else None, groups=nb)
-        if r2 is not None and (pro or not fuse & 4):
+        # the residual rides in the split-K reduce pass where the second GEMM is split (deep stages); in a GEMM epilogue
+        # it was measured slower than the separate add (bit 4)
+        split2 = REDUCE_ADD and N._ksplit(x2.shape[0], w2.shape[0], w2.shape[1]) > 1
+        add_in = r2 is not None and r2.is_contiguous() and (split2 or (bool(fuse & 4) and not pro))
+        y = N.gemm_split(t if pro else h, _packed(w2, caches[1], "lin_fwd", False, terms), bias=b2, amax=a2, groups=nb,
+                         a_gelu=pro, addend=r2 if add_in else None)
+        if r2 is not None and not add_in:
             y += r2
         ctx.fuse = fuse
         ctx.save_for_backward(t)

@@ -248,6 +248,12 @@ def test_split_k_for_small_tile_grids(N, terms):
         assert torch.equal(out, N.gemm_split(A, P, bias=b, relu=True))         # fixed summation order
         if word is not None:
             assert word.view(torch.float32).item() == out.abs().max().item()
+        # the reduce pass adds a residual; prologues apply per K slice
+        res = torch.randn(M, Nn, generator=g, device="cuda")
+        torch.testing.assert_close(N.gemm_split(A, P, bias=b, addend=res), N.gemm_split(A, P, bias=b) + res, rtol=0,
+                                   atol=1e-6 * scale)
+        ga, gb_ = N.gemm_split(A, P, a_gelu=True), N.gemm_split(torch.nn.functional.gelu(A), P)
+        torch.testing.assert_close(ga, gb_, rtol=0, atol=3e-6 * gb_.abs().max().item() if terms != 2 else 2e-5 * gb_.abs().max().item())
         # a row-strided output (column slice of a wider tensor)
         wide = torch.zeros(M, Nn + 64, device="cuda")
         N.gemm_split(A, P, bias=b, relu=True, out=wide[:, 32:32 + Nn])

@@ -406,6 +406,8 @@ typedef struct SeaGemmEpilogue {
   const float* a_gelu_grad_of; /* PROLOGUE instead of epilogue (exclusive with the fields above; terms 2 or 22): A is read as
                                 * A * GELU'(a_gelu_grad_of), same layout as A (lda, strideA): the GELU backward in front of the
                                 * first projection's input-gradient GEMM, applied while the tile is staged */
+  int a_gate;                  /* with a_gelu_grad_of: the tensor is a ReLU gate instead, A is read as (gate > 0 ? A : 0): the
+                                * backward of a fused GEMM + ReLU in front of its input-gradient GEMM */
   int a_gelu;                  /* PROLOGUE (exclusive with everything above): A is read as GELU(A): the activation in front of the
                                 * second projection's forward GEMM, without materialising GELU(A) */
 } SeaGemmEpilogue;

@@ -120,6 +120,7 @@ struct GemmSplitArgs {
   const float* gelu_grad_of;   // layout of C: the result is multiplied by GELU'(this)
   const float* a_gelu_grad_of; // layout of A: A is read as A * GELU'(this) (the backward of a GELU in front of the GEMM)
   int a_gelu;                  // A is read as GELU(A) (the GELU in front of the GEMM)
+  int a_gate;                  // a_gelu_grad_of is a ReLU gate instead: A is read as (gate > 0 ? A : 0)
 };
 
 // exact (erf) GELU and its derivative, the formulas of ATen's GeluCUDAKernelImpl / GeluBackwardCUDAKernelImpl
@@ -131,7 +132,7 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 }
 
 // EPI: the fused epilogue extras (addend / gelu_out / gelu_grad_of) are compiled in; PRO: the prologue factor GELU'(.) on A
-// (PRO = 1: A * GELU'(second operand); PRO = 2: GELU(A))
+// (PRO = 1: A * GELU'(second operand); PRO = 2: GELU(A); PRO = 3: second operand > 0 ? A : 0)
 template <int TERMS, bool S16, bool F16 = false, bool EPI = false, int PRO = 0>
 __global__ __launch_bounds__(256, 3) void gemm_split_kernel(const GemmSplitArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * TERMS * GS_IMG];
@@ -200,14 +201,14 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(const GemmSplitArgs 
   const uint32_t woff = (uint32_t)tid * 16;
 
   f32x4 pa[4];
-  f32x4 pt[PRO == 1 ? 4 : 1];
-  const char* const Tbase = PRO == 1 ? (const char*)(p.a_gelu_grad_of + (int64_t)g * p.strideA) : nullptr;
+  f32x4 pt[(PRO == 1 || PRO == 3) ? 4 : 1];
+  const char* const Tbase = (PRO == 1 || PRO == 3) ? (const char*)(p.a_gelu_grad_of + (int64_t)g * p.strideA) : nullptr;
   u32x4 pw[2 * TERMS];
   auto fetch = [&](int kb) {
     const char* a = Abase + (int64_t)kb * (GS_BK * 4);
 #pragma unroll
     for (int i = 0; i < 4; ++i) pa[i] = *(const f32x4*)(a + aoff[i]);
-    if constexpr (PRO == 1) {
+    if constexpr (PRO == 1 || PRO == 3) {
       const char* t = Tbase + (int64_t)kb * (GS_BK * 4);
 #pragma unroll
       for (int i = 0; i < 4; ++i) pt[i] = *(const f32x4*)(t + aoff[i]);
@@ -227,6 +228,10 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(const GemmSplitArgs 
       if constexpr (PRO == 2) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) pa[i][e] = gelu_f(pa[i][e]);
+      }
+      if constexpr (PRO == 3) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pa[i][e] = pt[i][e] > 0.f ? pa[i][e] : 0.f;
       }
       if constexpr (F16)
         split4_f16(pa[i], a_sc[i], s);
@@ -765,6 +770,7 @@ static int gemm_split_impl(const float* A, int64_t lda, const void* Wp, float* C
   p.gelu_grad_of = epi ? epi->gelu_grad_of : nullptr;
   p.a_gelu_grad_of = epi ? epi->a_gelu_grad_of : nullptr;
   p.a_gelu = epi ? epi->a_gelu : 0;
+  p.a_gate = epi ? epi->a_gate : 0;
   p.w_inv = terms == 22 ? (const float*)((const char*)Wp + (int64_t)(K / GS_BK) * 2 * gs_npad(N) * GS_BK * 2) : nullptr;
   const dim3 grid(p.per_xcd * 8), block(256);
   // MFMA shape: v_mfma_f32_32x32x16_bf16 fragments (default); SEA_GEMM_SHAPE=16 selects v_mfma_f32_16x16x32_bf16
@@ -786,6 +792,13 @@ static int gemm_split_impl(const float* A, int64_t lda, const void* Wp, float* C
   }
   if (p.a_gelu_grad_of) {   // prologue variant: two bf16 terms (the input-gradient mode) or fp16 x 2
     SEA_CHECK_ARG(!fused && (terms == 2 || terms == 22) && (((uintptr_t)p.a_gelu_grad_of) & 15) == 0);
+    if (p.a_gate) {
+      if (terms == 22)
+        hipLaunchKernelGGL((gemm_split_kernel<2, false, true, false, 3>), grid, block, 0, (hipStream_t)stream, p);
+      else
+        hipLaunchKernelGGL((gemm_split_kernel<2, false, false, false, 3>), grid, block, 0, (hipStream_t)stream, p);
+      SEA_RETURN_LAST();
+    }
     if (terms == 22)
       hipLaunchKernelGGL((gemm_split_kernel<2, false, true, false, 1>), grid, block, 0, (hipStream_t)stream, p);
     else

@@ -792,7 +792,7 @@ def _ksplit_workspace(device, numel):
 
 class _GemmEpilogue(C.Structure):       # SeaGemmEpilogue of include/sea_hip.h
     _fields_ = [("addend", C.c_void_p), ("ld_addend", C.c_int64), ("stride_addend", C.c_int64),
-                ("gelu_out", C.c_void_p), ("gelu_grad_of", C.c_void_p), ("a_gelu_grad_of", C.c_void_p), ("a_gelu", C.c_int)]
+                ("gelu_out", C.c_void_p), ("gelu_grad_of", C.c_void_p), ("a_gelu_grad_of", C.c_void_p), ("a_gate", C.c_int), ("a_gelu", C.c_int)]
 
 
 def _amax_words(A3, M, K, G, sA, groups):
@@ -805,7 +805,7 @@ def _amax_words(A3, M, K, G, sA, groups):
 
 def gemm_split(A, Wp: PackedWeight, bias=None, relu: bool = False, out=None, amax=None, out_amax=None, addend=None,
                gelu_out=None, gelu_grad_of=None, amax_rows: int = 0, groups: int = 1, a_gelu_grad_of=None,
-               a_gelu: bool = False):
+               a_gelu: bool = False, a_relu_gate=None):
     """out (.., N) = A (.., K) @ W^T [+ bias] [ReLU] with W pre-split (``gemm_split_pack``).  A: fp32, last dim
     contiguous; 2-D (M, K) with any 4-aligned row stride, or (G, M, K) against a batch of G packed weights.
     fp16 x 2 weights (terms 22): ``amax`` = device words holding the float bits of (upper bounds of) max|A|, one per
@@ -815,7 +815,13 @@ def gemm_split(A, Wp: PackedWeight, bias=None, relu: bool = False, out=None, ama
     Fused epilogue (sea_gemm_split_fused): ``addend`` (shape of out, last dim contiguous) is added before the activation;
     ``gelu_out`` (layout of out) receives GELU(out) while out keeps the pre-activation; the result is multiplied by
     GELU'(``gelu_grad_of``) (layout of out).  Prologue instead (exclusive): A is read as A * GELU'(``a_gelu_grad_of``)
-    (same shape and strides as A; terms 2 or 22), or as GELU(A) (``a_gelu``)."""
+    (same shape and strides as A; terms 2 or 22), as (``a_relu_gate`` > 0 ? A : 0) (same layout), or as GELU(A)
+    (``a_gelu``)."""
+    gate = a_relu_gate is not None
+    if gate:
+        if a_gelu_grad_of is not None:
+            raise SeaNativeError("gemm_split: a_relu_gate and a_gelu_grad_of are exclusive")
+        a_gelu_grad_of = a_relu_gate
     _dev(A, bias, out, addend, gelu_out, gelu_grad_of, a_gelu_grad_of)
     batched = Wp.batch > 1 or A.dim() == 3
     A3 = A if A.dim() == 3 else A.unsqueeze(0)
@@ -851,8 +857,8 @@ def gemm_split(A, Wp: PackedWeight, bias=None, relu: bool = False, out=None, ama
             part = _ksplit_workspace(A.device, S * M * Wp.N).view(S, M, Wp.N)
             shape, strides = (S, M, K // S), (K // S, A3.stride(1), 1)
             gemm_split(A3[0].as_strided(shape, strides), Wp.k_slices(S), out=part, amax=amax, amax_rows=amax_rows,
-                       a_gelu_grad_of=None if a_gelu_grad_of is None else a_gelu_grad_of.as_strided(shape, strides),
-                       a_gelu=a_gelu)
+                       a_gelu_grad_of=None if (a_gelu_grad_of is None or gate) else a_gelu_grad_of.as_strided(shape, strides),
+                       a_gelu=a_gelu, **({"a_relu_gate": a_gelu_grad_of.as_strided(shape, strides)} if gate else {}))
             _check(lib().sea_gemm_splitk_reduce(_p(part), S, M, Wp.N, _p(bias), _p(addend),
                                                 addend.stride(0) if addend is not None else 0, int(relu), _p(O3), O3.stride(1),
                                                 _p(out_amax) if Wp.terms == 22 else None, _stream()), "sea_gemm_splitk_reduce")
@@ -872,6 +878,7 @@ def gemm_split(A, Wp: PackedWeight, bias=None, relu: bool = False, out=None, ama
                 setattr(epi, name, T3.data_ptr())
         if a_gelu_grad_of is not None:
             epi.a_gelu_grad_of = a_gelu_grad_of.data_ptr()
+            epi.a_gate = int(gate)
         epi.a_gelu = int(bool(a_gelu))
         if Wp.terms == 22 and amax is None:
             amax, amax_rows = _amax_words(A3, M, K, G, sA, groups)

@@ -375,6 +375,7 @@ def _linear_frozen(mod_cache, x, w, b, amax=None, out_amax=None):
 #       waves per SIMD behind the accumulators (64 scalar accesses per lane).  Kept as tested options of the C ABI.
 #  16 = GELU applied to the A tile of the second projection's forward GEMM while it is staged: GELU(t) is never written.
 FUSE_MLP = int(os.environ.get("SEA_FUSE_MLP", "24"))
+RELU_GATE_PROLOGUE = os.environ.get("SEA_RELU_GATE_PROLOGUE", "1") != "0"   # A/B: 1x1 ConvModule backward (see _PointwiseRelu)
 REDUCE_ADD = os.environ.get("SEA_REDUCE_ADD", "1") != "0"   # A/B: the residual in the split-K reduce pass
 FUSE_PROLOGUE_MAX_NBLOCKS = int(os.environ.get("SEA_FUSE_PRO_NB", "3"))
 
@@ -802,9 +803,15 @@ class _PointwiseRelu(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         (y,) = ctx.saved_tensors
+        terms = _bwd_terms(ctx.terms)
+        if (RELU_GATE_PROLOGUE and terms in (2, 22) and gy.is_contiguous() and gy.dtype == torch.float32
+                and _split_ok(gy, ctx.w.shape[0], terms)):
+            # the ReLU gate is applied to the A tile of the input-gradient GEMM while it is staged: no masked copy of gy
+            from .. import _native as N
+            return (N.gemm_split(gy, _packed(ctx.w, ctx.cache, "pw_bwd", True, terms), a_relu_gate=y, groups=ctx.groups), None,
+                    None, None, None)
         g = torch.where(y > 0, gy, torch.zeros((), dtype=gy.dtype, device=gy.device))
-        return (_frozen_mm(g, ctx.w, ctx.cache, "pw_bwd", trans=True, terms=_bwd_terms(ctx.terms), groups=ctx.groups), None, None,
-                None, None)
+        return (_frozen_mm(g, ctx.w, ctx.cache, "pw_bwd", trans=True, terms=terms, groups=ctx.groups), None, None, None, None)
 
 
 class ConvModule(nn.Module):

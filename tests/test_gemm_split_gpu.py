@@ -211,6 +211,9 @@ def test_fused_epilogue_addend_gelu_and_gelu_grad(N, terms):
         wideA, wideS = torch.zeros(M, K + 32, device="cuda"), torch.zeros(M, K + 32, device="cuda")
         wideA[:, 16:16 + K], wideS[:, 16:16 + K] = A, sA
         assert torch.equal(N.gemm_split(wideA[:, 16:16 + K], P, a_gelu_grad_of=wideS[:, 16:16 + K]), got)
+        # prologue: ReLU gate (the backward of a fused GEMM + ReLU): bitwise the GEMM on the masked copy
+        gate = torch.randn(M, K, generator=g, device="cuda")
+        assert torch.equal(N.gemm_split(A, P, a_relu_gate=gate), N.gemm_split(torch.where(gate > 0, A, torch.zeros_like(A)), P))
     else:
         with pytest.raises(N.SeaNativeError):
             N.gemm_split(A, P, a_gelu_grad_of=A)

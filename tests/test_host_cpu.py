@@ -183,3 +183,56 @@ def test_folded_batchnorm_and_frozen_parameter_scope():
         with _FrozenParameters(mod):
             raise RuntimeError("forward failed")
     assert [p.requires_grad for p in mod.parameters()] == flags
+
+
+def test_split_k_policy(native):
+    """which GEMMs run as a batch of K slices (semseg/_native.py:_ksplit): few 128 x 128 tiles, long K, slices of whole
+    32-deep K steps, at least 8 of them per slice; everything else single pass"""
+    N = native
+    for M, Nn, K, want in ((2048, 768, 3072, 8), (8192, 384, 1536, 4), (2048, 512, 4608, 12), (8192, 512, 4608, 3),
+                           (2048, 3072, 768, 2), (131072, 384, 96, 1), (8192, 1536, 384, 1), (2048, 768, 128, 1),
+                           (2048, 770, 3072, 1), (32768, 192, 768, 1)):
+        S = N._ksplit(M, Nn, K)
+        assert S == want, (M, Nn, K, S)
+        assert S == 1 or ((K // 32) % S == 0 and K // 32 // S >= N.KSPLIT_MIN_KB)
+    keep, N.KSPLIT = N.KSPLIT, False
+    try:
+        assert N._ksplit(2048, 768, 3072) == 1
+    finally:
+        N.KSPLIT = keep
+
+
+def test_analytic_activation_bounds_hold():
+    """the fp16 x 2 activation scales that need no pass over the activations (convnext_upernet._ln_bound_word /
+    _linear_bound_word): float bits of an UPPER bound of |LayerNorm(x)|, and of |x W^T + b| for any x within the input
+    bound (hence of GELU / ReLU of it and of convex combinations of its rows)"""
+    from semseg.models import convnext_upernet as M
+    g = torch.Generator().manual_seed(3)
+    for C in (96, 384):
+        ln = torch.nn.LayerNorm(C, eps=1e-6)
+        with torch.no_grad():
+            ln.weight.copy_(torch.randn(C, generator=g) * 2)
+            ln.bias.copy_(torch.randn(C, generator=g))
+        lin = torch.nn.Linear(C, 4 * C)
+        with torch.no_grad():
+            lin.weight.copy_(torch.randn(4 * C, C, generator=g) / C ** 0.5)
+            lin.bias.copy_(torch.randn(4 * C, generator=g))
+        cache = {}
+        w_ln = M._ln_bound_word(ln, cache)
+        w_lin = M._linear_bound_word(w_ln, lin.weight, lin.bias, cache)
+        assert w_ln.dtype == torch.int32 and w_ln.numel() == 1 and M._ln_bound_word(ln, cache) is w_ln   # cached
+        b_ln, b_lin = w_ln.view(torch.float32).item(), w_lin.view(torch.float32).item()
+        worst_ln = worst_lin = 0.0
+        for scale, spike in ((1.0, 0.0), (1e-3, 0.0), (50.0, 0.0), (1.0, 1e4)):        # incl. one dominant channel: the
+            x = torch.randn(512, C, generator=g) * scale                                # sqrt(C) extreme of a LayerNorm
+            x[:, 7] += spike
+            with torch.no_grad():
+                y = ln(x)
+                t = lin(y)
+            worst_ln, worst_lin = max(worst_ln, y.abs().max().item()), max(worst_lin, t.abs().max().item())
+            assert torch.nn.functional.gelu(t).abs().max().item() <= t.abs().max().item() + 1e-6
+        assert worst_ln <= b_ln and worst_lin <= b_lin
+        assert b_ln <= 40 * worst_ln and b_lin <= 2 ** 10 * worst_lin                  # loose, but inside the free range
+        with torch.no_grad():
+            ln.weight.mul_(3.0)                                                         # in-place change: re-derived
+        assert M._ln_bound_word(ln, cache).view(torch.float32).item() > b_ln

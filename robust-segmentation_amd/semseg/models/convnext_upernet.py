@@ -321,13 +321,15 @@ def _linear_bound_word(in_word, w, b, cache):
     (``in_word``: float bits of that bound), hence of GELU / ReLU of it and of any convex combination of its rows (attention).
     The fp16 x 2 scale of the NEXT GEMM without a pass over the activations and without any dependence on the batch.
     Cached until the weights change."""
-    key = (_tkey(w, b), in_word.data_ptr())
-    if cache.get("lin_bound_key") != key:
+    key = _tkey(w, b)
+    # (the input word is compared by identity and kept referenced: a re-derived word can then never reuse its address)
+    if cache.get("lin_bound_key") != key or cache.get("lin_bound_in") is not in_word:
         with torch.no_grad():
             bnd = in_word.view(torch.float32) * w.abs().sum(1)
             if b is not None:
                 bnd = bnd + b.abs()
-            cache.update(lin_bound_key=key, lin_bound=bnd.max().float().reshape(1).contiguous().view(torch.int32))
+            cache.update(lin_bound_key=key, lin_bound_in=in_word,
+                         lin_bound=bnd.max().float().reshape(1).contiguous().view(torch.int32))
     return cache["lin_bound"]
 
 

@@ -235,4 +235,6 @@ def test_analytic_activation_bounds_hold():
         assert b_ln <= 40 * worst_ln and b_lin <= 2 ** 10 * worst_lin                  # loose, but inside the free range
         with torch.no_grad():
             ln.weight.mul_(3.0)                                                         # in-place change: re-derived
-        assert M._ln_bound_word(ln, cache).view(torch.float32).item() > b_ln
+        w_ln2 = M._ln_bound_word(ln, cache)
+        assert w_ln2.view(torch.float32).item() > b_ln
+        assert M._linear_bound_word(w_ln2, lin.weight, lin.bias, cache).view(torch.float32).item() > b_lin   # follows its input

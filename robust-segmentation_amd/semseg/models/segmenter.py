@@ -106,16 +106,21 @@ class FeedForward(nn.Module):
         self.fc2 = nn.Linear(hidden, dim)
         self.drop = nn.Dropout(dropout)
 
-    def forward(self, x, amax=None):
+    def forward(self, x, amax=None, res=None):
+        """``res`` (optional, shape of x): returns res + mlp(x) (the block's residual rides in the second GEMM's split-K
+        reduce pass on the fused path)"""
         gc = self.__dict__.setdefault("_gemm_cache", ({}, {}))
         a2 = None
         if amax is not None and not (self.fc1.weight.requires_grad or self.fc1.bias.requires_grad):
             a2 = _linear_bound_word(amax, self.fc1.weight, self.fc1.bias, gc[0])   # |GELU(t)| <= |t| <= bound of the first GEMM
         if ((not self.training or self.drop.p == 0.0) and self.act.approximate == "none"
                 and _cu._mlp_fusable(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)):
-            return _cu._FrozenMlp.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, None, gc, amax, a2)
+            r = res if (res is not None and res.is_contiguous()) else None
+            y = _cu._FrozenMlp.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, r, gc, amax, a2)
+            return y if (res is None or r is not None) else res + y
         h = self.drop(self.act(_linear_frozen(gc[0], x, self.fc1.weight, self.fc1.bias, amax=amax)))
-        return self.drop(_linear_frozen(gc[1], h, self.fc2.weight, self.fc2.bias, amax=a2))
+        out = self.drop(_linear_frozen(gc[1], h, self.fc2.weight, self.fc2.bias, amax=a2))
+        return out if res is None else res + out
 
 
 class Block(nn.Module):
@@ -138,6 +143,8 @@ class Block(nn.Module):
 
     def forward(self, x):
         x = x + self.drop_path(self.attn(self.norm1(x), self._bound(self.norm1, x, 0)))
+        if isinstance(self.drop_path, nn.Identity) or not self.training:
+            return self.mlp(self.norm2(x), self._bound(self.norm2, x, 1), res=x)
         return x + self.drop_path(self.mlp(self.norm2(x), self._bound(self.norm2, x, 1)))
 
 

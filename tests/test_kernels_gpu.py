@@ -964,6 +964,10 @@ def test_block_mlp_with_fused_epilogues_matches_the_unfused_pair(N, terms):
             assert y1.stride() == y0.stride()
         if mask == 0:
             assert torch.equal(y1, y0)
+    # Segmenter's block hands its residual to the feed-forward (it rides in the split-K reduce pass of the second GEMM)
+    with M._gemm_terms(terms):
+        r0 = torch.randn_like(xf)
+        torch.testing.assert_close(ff(xf, res=r0), r0 + ff(xf), rtol=0, atol=1e-6 * (r0 + ff(xf)).abs().max().item())
 
 
 # ------------------------------------------------------------------------------------------------ full-size ADE workloads

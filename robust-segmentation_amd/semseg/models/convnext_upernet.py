@@ -393,10 +393,12 @@ def _mlp_fusable(x, w1, b1, w2, b2):
 
 class _FrozenMlp(torch.autograd.Function):
     """res + W2 GELU(W1 x + b1) + b2 for frozen (W1, b1, W2, b2) (the MLP of a ConvNeXt / ViT block, reference
-    convnext_orig.py:38-58, vit_encoder.py:41-60), input gradient only.  Two M8 GEMMs each way; GELU runs in the epilogue
-    of the first forward GEMM (which keeps the pre-activation for the backward), GELU' in the epilogue of the first
-    backward GEMM, the residual add in the epilogue of the second forward GEMM: no element-wise pass over the 4C-wide
-    hidden tensor in either direction."""
+    convnext_orig.py:38-58, vit_encoder.py:41-60), input gradient only.  Two M8 GEMMs each way.  By default (FUSE_MLP
+    bits 8 + 16) the element-wise neighbours are PROLOGUES of the consuming GEMMs: the second forward GEMM reads the
+    pre-activation t and applies GELU to its A tile while staging it, the first projection's input-gradient GEMM reads the
+    incoming gradient and t and multiplies by GELU'(t) the same way; the residual rides in the split-K reduce pass where the
+    second forward GEMM is split.  Only t is kept for the backward; GELU(t) and g * GELU'(t) are never written.  The
+    epilogue variants (bits 1, 2, 4) were measured slower and are off."""
 
     @staticmethod
     @_fp32_fwd

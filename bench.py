@@ -313,7 +313,9 @@ def main():
                 "hip_graph": bool(run.graphs is not None),
                 "gemm": ("sea_gemm_split: forward products " + ("fp16x2 split MFMA (22 significant bits per operand, 3 products)"
                          if GEMM_TERMS == 22 else f"bf16x{GEMM_TERMS} split MFMA") + ", input-gradient products bf16x"
-                         + str(GEMM_TERMS_BWD if GEMM_TERMS == 22 else min(GEMM_TERMS, GEMM_TERMS_BWD)) + ", fp32 accumulate")
+                         + str(GEMM_TERMS_BWD if GEMM_TERMS == 22 else min(GEMM_TERMS, GEMM_TERMS_BWD)) + ", fp32 accumulate"
+                         + "; per-row power-of-two activation scales, split-K for small tile grids, GELU / GELU' / ReLU-gate"
+                         + " prologues")
                 if GEMM_TERMS in (2, 3, 22) else "hipBLASLt fp32",
                 **({"per_rank": per_rank} if per_rank else {}),
             },

@@ -238,3 +238,23 @@ def test_analytic_activation_bounds_hold():
         w_ln2 = M._ln_bound_word(ln, cache)
         assert w_ln2.view(torch.float32).item() > b_ln
         assert M._linear_bound_word(w_ln2, lin.weight, lin.bias, cache).view(torch.float32).item() > b_lin   # follows its input
+
+
+def test_gemm_epilogue_struct_matches_the_header(native):
+    """the ctypes mirror of SeaGemmEpilogue (semseg/_native.py) lists the fields of include/sea_hip.h in the same order
+    with the same C types: the struct crosses the ABI by pointer"""
+    import ctypes
+    src = open(os.path.join(ROOT, "include", "sea_hip.h")).read()
+    body = re.search(r"typedef struct SeaGemmEpilogue \{(.*?)\} SeaGemmEpilogue;", src, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        ctype, names = decl.rsplit(" ", 1)[0], decl
+        m = re.match(r"(const float\*|float\*|int64_t|int)\s+(.*)", decl)
+        assert m, decl
+        kind = {"const float*": ctypes.c_void_p, "float*": ctypes.c_void_p, "int64_t": ctypes.c_int64, "int": ctypes.c_int}[m.group(1)]
+        fields += [(n.strip(), kind) for n in m.group(2).split(",")]
+    assert [(n, t) for n, t in native._GemmEpilogue._fields_] == fields

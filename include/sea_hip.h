@@ -378,7 +378,8 @@ int sea_gemm_split_f16(const float* A, int64_t lda, const void* Wp, float* C, in
  * word per image (amax_rows = rows of an image) or per row, an image's result does not depend on the images it shares a
  * batch with -- a per-tensor scale moves the sub-normal cut-off of the low fp16 term with the batch maximum, which changes
  * last bits and was measured to break the sharded evaluation's bitwise 1-rank == 2-rank property.
- * sea_absmax_bits(rows_per_word) computes the words exactly (rows_per_word = 0: one word); producers can supply them for
+ * sea_absmax_bits(rows_per_word) computes the words exactly (rows_per_word = 0: one word; 1: one word per row, one writer
+ * per word -- the scales of a GRADIENT operand, whose rows span many orders of magnitude); producers can supply them for
  * free: sea_wino_input_transform_amax (one word per tile), analytic bounds (LayerNorm output: sqrt(C) max|w| + max|b|; a
  * GEMM's output: bound(input) * max_n ||W_n||_1 + max|bias|), or the out_amax word (whole-tensor max|C|) of the GEMM whose
  * output feeds a non-expanding element-wise function.  A loose bound costs nothing up to a factor ~2^10 (fp16 is floating
@@ -410,6 +411,9 @@ typedef struct SeaGemmEpilogue {
                                 * backward of a fused GEMM + ReLU in front of its input-gradient GEMM */
   int a_gelu;                  /* PROLOGUE (exclusive with everything above): A is read as GELU(A): the activation in front of the
                                 * second projection's forward GEMM, without materialising GELU(A) */
+  float a_amax_mul;            /* terms 22, > 0: the amax_bits words bound max|A| only after multiplication by this constant (a
+                                * producer-side per-row bound carried through the GEMM in between: rowmax(g) * max_n ||W_n||_1,
+                                * times max|GELU'| = 1.13 for the a_gelu_grad_of prologue); 0 = 1: the words as they are */
 } SeaGemmEpilogue;
 int sea_gemm_split_fused(const float* A, int64_t lda, const void* Wp, float* C, int64_t ldc, const float* bias, int relu, int M,
                          int N, int K, int terms, int batch, int64_t strideA, int64_t strideW_bytes, int64_t strideC,

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Worst-case SEA tables of the REAL reference for the north_star's second metric (build container only).
 
-    python oracle/gen_miou_reference.py --parts 0 1 2 3 [--eps255 8] [--n-iter 100] [--threads 4]
+    python oracle/gen_miou_reference.py --parts 0 1 2 3 [--eps255 8] [--n-iter 100] [--threads 4] [--tag _t3]
 
 Runs nmndeep/Robust-Segmentation itself (semseg.attacker.apgd_largereps x the three SEA losses, then
 tools.worse_only.evalSEA, reference tools/infer.py:332-408 and tools/worse_only.py:181-422) on CPU, on PARTS of 64
@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--n-iter", type=int, default=100)
     ap.add_argument("--threads", type=int, default=4)
     ap.add_argument("--limit", type=int, default=PART, help="images of the part to run (timing probes)")
+    ap.add_argument("--tag", default="", help="file-name suffix of a RE-RUN of an existing part with another thread count "
+                    "(reference-vs-reference noise floor, tests/test_miou_claim_gpu.py), e.g. --threads 3 --tag _t3")
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(args.threads)
@@ -160,7 +162,8 @@ def main():
             st = torch.load(os.path.join(td, "test_results", f"stats_SEA_ref_{args.eps255}.pt"))
         P = torch.stack(preds)
         correct = (P == labels[None]).flatten(2).sum(-1)                       # (A, n) correct pixels per attack
-        name = f"part_{part:02d}_eps{int(args.eps255)}" + ("" if n == PART else f"_n{n}")
+        name = (f"part_{part:02d}_eps{int(args.eps255)}" + ("" if n == PART else f"_n{n}")
+                + ("" if args.n_iter == 100 else f"_it{args.n_iter}") + args.tag)
         np.savez_compressed(
             os.path.join(OUT, name + ".npz"), labels=labels.to(torch.uint8).numpy(), n_iter=np.int64(args.n_iter),
             eps255=np.float64(args.eps255), part=np.int64(part), ints=st["run_int_imwise"].to(torch.int32).numpy(),

@@ -362,11 +362,11 @@ int sea_attention_bwd_bf16(const float* q, const float* k, const float* v, int64
                            float* dv, int64_t gsb, int64_t gsh, int64_t gst, int terms, hipStream_t stream);
 
 // SEA_ATTN_TERMS (forward) / SEA_ATTN_TERMS_BWD: 3 or 2 = bf16 terms per operand on v_mfma_f32_32x32x16_bf16, 0 = the fp32
-// MFMA kernels of this file.  Defaults: 3 (= the fp32 operands exactly) forward, 2 backward (the attack consumes only the
-// sign of the input gradient).
+// MFMA kernels of this file.  Defaults: 3 (= the fp32 operands exactly) forward AND backward (round 4: the evaluation is
+// fp32-equivalent end to end; 2 backward was round 3's default: the attack consumes only the sign of the input gradient).
 static inline int attn_terms(bool backward) {   // looked up per call (two launches per layer): tests switch it in-process
   const char* e = getenv(backward ? "SEA_ATTN_TERMS_BWD" : "SEA_ATTN_TERMS");
-  const int t = e ? atoi(e) : (backward ? 2 : 3);
+  const int t = e ? atoi(e) : 3;
   return (t == 2 || t == 3) ? t : 0;
 }
 

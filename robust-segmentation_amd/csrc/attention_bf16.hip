@@ -432,8 +432,13 @@ int sea_attention_bwd_bf16(const float* q, const float* k, const float* v, int64
   AttnPtrsB p{q, k, v, sb, sh, st};
   dim3 grid((T + 127) / 128, H, B), block(256);
   const size_t lds = (size_t)4 * terms * kImg + 2 * kTile * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {  // 4 x 3 x 8 KB = 96 KB of dynamic LDS at three terms: opt in once per process
+  // 4 x 3 x 8 KB = 96 KB of dynamic LDS at three terms: opt in once per DEVICE (the attribute is per device; a process that
+  // drives a second GPU would otherwise fail its first dkv launch there)
+  static bool attr_set_dev[64] = {};
+  int dev = 0;
+  hipGetDevice(&dev);
+  bool& attr_set = attr_set_dev[dev & 63];
+  if (!attr_set) {
     hipFuncSetAttribute((const void*)attn_dkv_bf16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 3 * kImg + 512);
     hipFuncSetAttribute((const void*)attn_dkv_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * kImg + 512);
     hipFuncSetAttribute((const void*)attn_dq_bf16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * kImg);

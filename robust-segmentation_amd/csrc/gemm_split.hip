@@ -111,6 +111,8 @@ struct GemmSplitArgs {
   int relu;
   const uint32_t* amax_bits;   // fp16 x 2 only: float bits of max |A| (device memory): one word, or one per amax_rows rows
   int amax_rows;
+  float amax_mul;              // fp16 x 2 only: the words bound max|A| / amax_mul (a producer-side bound times a constant of the
+                               // consumer: ||W||_1 of the GEMM in between, max|GELU'|); 1 = the words as they are
   const float* w_inv;          // fp16 x 2 only: per-column inverse weight scale
   uint32_t* out_amax;          // optional: atomic max of the float bits of |C| (pre-zeroed word), for a consumer GEMM
   // fused epilogue extras (sea_gemm_split_fused): all optional
@@ -179,7 +181,9 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(const GemmSplitArgs 
       int row = m0 + tid;
       row = row < M ? row : M - 1;
       float sc, inv;
-      pow2_scale(p.amax_bits[p.amax_rows > 0 ? row / p.amax_rows : 0], sc, inv);
+      uint32_t word = p.amax_bits[p.amax_rows > 0 ? row / p.amax_rows : 0];
+      if (p.amax_mul != 1.f) word = __float_as_uint(__uint_as_float(word) * p.amax_mul) & 0x7fffffffu;
+      pow2_scale(word, sc, inv);
       row_sc[tid] = sc;
       row_inv[tid] = inv;
     }
@@ -572,6 +576,41 @@ __global__ __launch_bounds__(256) void absmax_groups_kernel(const float* __restr
   }
 }
 
+// out[r] = float bits of max_k |A[r][k]|: ONE WORD PER ROW (the fp16 x 2 scale of a gradient operand, whose rows -- pixels --
+// span many orders of magnitude).  LPR lanes share a row (LPR = 8 .. 64, a power of two), 256 / LPR rows per block; every
+// word has one writer: no atomics, no zero fill, any grid.  Four independent 16-byte loads in flight per lane.
+template <int LPR>
+__global__ __launch_bounds__(256) void rowmax_rows_kernel(const float* __restrict__ A, int64_t lda, int M, int K4,
+                                                          uint32_t* __restrict__ out) {
+  constexpr int RPB = 256 / LPR;
+  const int j = threadIdx.x % LPR, rl = threadIdx.x / LPR;
+  for (int64_t r0 = (int64_t)blockIdx.x * RPB; r0 < M; r0 += (int64_t)gridDim.x * RPB) {
+    const int64_t row = r0 + rl;
+    uint32_t m = 0;
+    if (row < M) {
+      const f32x4* p = reinterpret_cast<const f32x4*>(A + row * lda);
+      const int last = K4 - 1;
+      for (int k = j; k < K4; k += 4 * LPR) {
+        const int k1 = k + LPR, k2 = k + 2 * LPR, k3 = k + 3 * LPR;   // (clamped duplicates are harmless for a maximum)
+        const f32x4 v0 = p[k], v1 = p[k1 < last ? k1 : last], v2 = p[k2 < last ? k2 : last], v3 = p[k3 < last ? k3 : last];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t b0 = __float_as_uint(v0[e]) & 0x7fffffffu, b1 = __float_as_uint(v1[e]) & 0x7fffffffu;
+          const uint32_t b2 = __float_as_uint(v2[e]) & 0x7fffffffu, b3 = __float_as_uint(v3[e]) & 0x7fffffffu;
+          const uint32_t a = b0 > b1 ? b0 : b1, b = b2 > b3 ? b2 : b3, c = a > b ? a : b;
+          m = c > m ? c : m;
+        }
+      }
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) {
+      const uint32_t other = (uint32_t)__shfl_xor((int)m, o, 64);
+      m = other > m ? other : m;
+    }
+    if (j == 0 && row < M) out[row] = m;
+  }
+}
+
 // zero-fill of a few words as a KERNEL: inside a captured HIP graph a hipMemsetAsync node was observed to run out of order
 // with the neighbouring kernel nodes (the max|A| word was cleared after sea_absmax_bits had accumulated into it: replays
 // differed from the eager loop on 1 of 6 runs with 8 such nodes per graph, on 6 of 6 with 48)
@@ -711,6 +750,22 @@ extern "C" int sea_absmax_bits(const float* A, int64_t lda, int M, int K, int ba
                                uint32_t* out_bits, void* stream) {
   SEA_CHECK_ARG(A && out_bits && M > 0 && K > 0 && (K % 4) == 0 && (lda % 4) == 0 && batch > 0 && (((uintptr_t)A) & 15) == 0);
   SEA_CHECK_ARG(rows_per_word >= 0);
+  if (rows_per_word == 1 && batch == 1) {
+    // one word per row: the scales of a GRADIENT operand (sea_gemm_split_f16 with amax_rows = 1)
+    const int K4 = K / 4;
+    const int lpr = K4 >= 64 ? 64 : (K4 >= 32 ? 32 : (K4 >= 16 ? 16 : 8));
+    const int64_t blocks = ((int64_t)M * lpr + 255) / 256;
+    const dim3 grid((unsigned)(blocks < 8192 ? blocks : 8192)), block(256);
+    if (lpr == 64)
+      hipLaunchKernelGGL(rowmax_rows_kernel<64>, grid, block, 0, (hipStream_t)stream, A, lda, M, K4, out_bits);
+    else if (lpr == 32)
+      hipLaunchKernelGGL(rowmax_rows_kernel<32>, grid, block, 0, (hipStream_t)stream, A, lda, M, K4, out_bits);
+    else if (lpr == 16)
+      hipLaunchKernelGGL(rowmax_rows_kernel<16>, grid, block, 0, (hipStream_t)stream, A, lda, M, K4, out_bits);
+    else
+      hipLaunchKernelGGL(rowmax_rows_kernel<8>, grid, block, 0, (hipStream_t)stream, A, lda, M, K4, out_bits);
+    SEA_RETURN_LAST();
+  }
   if (rows_per_word > 0 && rows_per_word < M) {
     // one word per group of rows_per_word consecutive rows (all batch entries): grid.y = group
     const int words = (M + rows_per_word - 1) / rows_per_word;
@@ -771,6 +826,7 @@ static int gemm_split_impl(const float* A, int64_t lda, const void* Wp, float* C
   p.a_gelu_grad_of = epi ? epi->a_gelu_grad_of : nullptr;
   p.a_gelu = epi ? epi->a_gelu : 0;
   p.a_gate = epi ? epi->a_gate : 0;
+  p.amax_mul = (epi && epi->a_amax_mul > 0.f) ? epi->a_amax_mul : 1.f;
   p.w_inv = terms == 22 ? (const float*)((const char*)Wp + (int64_t)(K / GS_BK) * 2 * gs_npad(N) * GS_BK * 2) : nullptr;
   const dim3 grid(p.per_xcd * 8), block(256);
   // MFMA shape: v_mfma_f32_32x32x16_bf16 fragments (default); SEA_GEMM_SHAPE=16 selects v_mfma_f32_16x16x32_bf16

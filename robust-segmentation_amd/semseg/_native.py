@@ -792,11 +792,17 @@ def _ksplit_workspace(device, numel):
 
 class _GemmEpilogue(C.Structure):       # SeaGemmEpilogue of include/sea_hip.h
     _fields_ = [("addend", C.c_void_p), ("ld_addend", C.c_int64), ("stride_addend", C.c_int64),
-                ("gelu_out", C.c_void_p), ("gelu_grad_of", C.c_void_p), ("a_gelu_grad_of", C.c_void_p), ("a_gate", C.c_int), ("a_gelu", C.c_int)]
+                ("gelu_out", C.c_void_p), ("gelu_grad_of", C.c_void_p), ("a_gelu_grad_of", C.c_void_p), ("a_gate", C.c_int), ("a_gelu", C.c_int),
+                ("a_amax_mul", C.c_float)]
 
 
-def _amax_words(A3, M, K, G, sA, groups):
-    """exact per-group maxima of |A| (float bits), one word per M / groups rows"""
+def _amax_words(A3, M, K, G, sA, groups, per_row=False):
+    """exact per-group maxima of |A| (float bits), one word per M / groups rows -- or one per ROW (``per_row``: gradient
+    operands, whose rows span many orders of magnitude)"""
+    if per_row and G == 1:
+        words = torch.empty(M, dtype=torch.int32, device=A3.device)
+        _check(lib().sea_absmax_bits(_p(A3), A3.stride(1), M, K, 1, 0, 1, _p(words), _stream()), "sea_absmax_bits")
+        return words, 1
     rpw = M // groups if (groups > 1 and M % groups == 0) else 0
     words = torch.empty(groups if rpw else 1, dtype=torch.int32, device=A3.device)
     _check(lib().sea_absmax_bits(_p(A3), A3.stride(1), M, K, G, sA, rpw, _p(words), _stream()), "sea_absmax_bits")
@@ -805,13 +811,15 @@ def _amax_words(A3, M, K, G, sA, groups):
 
 def gemm_split(A, Wp: PackedWeight, bias=None, relu: bool = False, out=None, amax=None, out_amax=None, addend=None,
                gelu_out=None, gelu_grad_of=None, amax_rows: int = 0, groups: int = 1, a_gelu_grad_of=None,
-               a_gelu: bool = False, a_relu_gate=None):
+               a_gelu: bool = False, a_relu_gate=None, row_amax: bool = False, amax_mul: float = 1.0):
     """out (.., N) = A (.., K) @ W^T [+ bias] [ReLU] with W pre-split (``gemm_split_pack``).  A: fp32, last dim
     contiguous; 2-D (M, K) with any 4-aligned row stride, or (G, M, K) against a batch of G packed weights.
     fp16 x 2 weights (terms 22): ``amax`` = device words holding the float bits of (upper bounds of) max|A|, one per
     ``amax_rows`` rows (0: one word for the tensor); computed here when None, one word per ``groups``-th of the rows (pass
     the number of images: an image's scale then does not depend on its batch partners); ``out_amax`` = pre-zeroed word that
-    receives the bits of max|out|.
+    receives the bits of max|out|.  ``row_amax``: the words computed here are one per ROW (sea_absmax_bits with
+    rows_per_word = 1).  ``amax_mul``: the supplied words bound max|A| only after multiplication by this constant (a per-row
+    bound of the producer's input carried through the producer: see SeaGemmEpilogue.a_amax_mul).
     Fused epilogue (sea_gemm_split_fused): ``addend`` (shape of out, last dim contiguous) is added before the activation;
     ``gelu_out`` (layout of out) receives GELU(out) while out keeps the pre-activation; the result is multiplied by
     GELU'(``gelu_grad_of``) (layout of out).  Prologue instead (exclusive): A is read as A * GELU'(``a_gelu_grad_of``)
@@ -840,8 +848,9 @@ def gemm_split(A, Wp: PackedWeight, bias=None, relu: bool = False, out=None, ama
     if amax is not None and (amax.dtype != torch.int32 or not amax.is_contiguous()
                              or amax.numel() < (-(-M // amax_rows) if amax_rows > 0 else 1)):
         raise SeaNativeError("gemm_split: amax must hold one int32 word per amax_rows rows")
+    amax_mul = float(amax_mul) if Wp.terms == 22 else 1.0
     fused = (addend is not None or gelu_out is not None or gelu_grad_of is not None or a_gelu_grad_of is not None
-             or a_gelu)
+             or a_gelu or amax_mul != 1.0)
     if a_gelu_grad_of is not None and (a_gelu_grad_of.shape != A.shape or a_gelu_grad_of.stride() != A.stride()
                                        or a_gelu_grad_of.dtype != torch.float32 or Wp.terms not in (2, 22)):
         raise SeaNativeError("gemm_split: a_gelu_grad_of must be float32 with A's shape and strides (terms 2 or 22)")
@@ -853,12 +862,13 @@ def gemm_split(A, Wp: PackedWeight, bias=None, relu: bool = False, out=None, ama
         S = _ksplit(M, Wp.N, K)
         if S > 1:
             if Wp.terms == 22 and amax is None:
-                amax, amax_rows = _amax_words(A3, M, K, 1, 0, groups)
+                amax, amax_rows = _amax_words(A3, M, K, 1, 0, groups, row_amax)
             part = _ksplit_workspace(A.device, S * M * Wp.N).view(S, M, Wp.N)
             shape, strides = (S, M, K // S), (K // S, A3.stride(1), 1)
             gemm_split(A3[0].as_strided(shape, strides), Wp.k_slices(S), out=part, amax=amax, amax_rows=amax_rows,
                        a_gelu_grad_of=None if (a_gelu_grad_of is None or gate) else a_gelu_grad_of.as_strided(shape, strides),
-                       a_gelu=a_gelu, **({"a_relu_gate": a_gelu_grad_of.as_strided(shape, strides)} if gate else {}))
+                       a_gelu=a_gelu, amax_mul=amax_mul,
+                       **({"a_relu_gate": a_gelu_grad_of.as_strided(shape, strides)} if gate else {}))
             _check(lib().sea_gemm_splitk_reduce(_p(part), S, M, Wp.N, _p(bias), _p(addend),
                                                 addend.stride(0) if addend is not None else 0, int(relu), _p(O3), O3.stride(1),
                                                 _p(out_amax) if Wp.terms == 22 else None, _stream()), "sea_gemm_splitk_reduce")
@@ -880,8 +890,9 @@ def gemm_split(A, Wp: PackedWeight, bias=None, relu: bool = False, out=None, ama
             epi.a_gelu_grad_of = a_gelu_grad_of.data_ptr()
             epi.a_gate = int(gate)
         epi.a_gelu = int(bool(a_gelu))
+        epi.a_amax_mul = amax_mul if amax_mul != 1.0 else 0.0
         if Wp.terms == 22 and amax is None:
-            amax, amax_rows = _amax_words(A3, M, K, G, sA, groups)
+            amax, amax_rows = _amax_words(A3, M, K, G, sA, groups, row_amax)
         _check(lib().sea_gemm_split_fused(_p(A3), A3.stride(1), _p(Wp.data), _p(O3), O3.stride(1), _p(bias), int(relu), M, Wp.N,
                                           K, Wp.terms, G, sA, Wp.stride, sC, _p(amax) if Wp.terms == 22 else None, amax_rows,
                                           _p(out_amax) if Wp.terms == 22 else None, C.addressof(epi), _stream()),
@@ -890,7 +901,7 @@ def gemm_split(A, Wp: PackedWeight, bias=None, relu: bool = False, out=None, ama
     if Wp.terms == 22:
         # fp16 x 2: the activation scale comes from max|A|, computed on the device (no host round trip)
         if amax is None:
-            amax, amax_rows = _amax_words(A3, M, K, G, sA, groups)
+            amax, amax_rows = _amax_words(A3, M, K, G, sA, groups, row_amax)
         _check(lib().sea_gemm_split_f16(_p(A3), A3.stride(1), _p(Wp.data), _p(O3), O3.stride(1), _p(bias), int(relu), M, Wp.N,
                                         K, G, sA, Wp.stride, sC, _p(amax), amax_rows, _p(out_amax), _stream()),
                "sea_gemm_split_f16")

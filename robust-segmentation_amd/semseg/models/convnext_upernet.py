@@ -235,11 +235,13 @@ GEMM_TERMS = int(os.environ.get("SEA_GEMM_TERMS", "22"))
 # Under bf16 autocast (PIR-AT's inner PGD with TRAIN.AMP, BASELINE configs[3]) the decode head's fp32 islands run M8 with
 # TWO terms: 16 significant bits per operand (twice bf16's) at three MFMA products instead of six.
 GEMM_TERMS_AUTOCAST = int(os.environ.get("SEA_GEMM_TERMS_AUTOCAST", "2"))
-# Terms of the INPUT-GRADIENT products.  The attack only uses sign(gradient) (attacker.py:396): 16-bit operands there
-# perturb gradient elements at the 1e-5 level of max|g|, i.e. where rounding already decides the sign (measured with the
-# teacher-forced fixtures, tests/test_teacher_forced_gpu.py), while losses, logits and arg-max maps come from the
-# forward products and keep all three terms.
-GEMM_TERMS_BWD = int(os.environ.get("SEA_GEMM_TERMS_BWD", "2"))
+# Terms of the INPUT-GRADIENT products.  Default 22 (round 4): fp16 x 2 like the forward -- 22 significant bits per operand,
+# error <= the fp32 GEMM's own -- so that the whole evaluation is fp32-equivalent, as the reference's is.  A gradient
+# operand's rows (pixels) span many orders of magnitude, so its power-of-two scales are PER ROW: exact row maxima
+# (sea_absmax_bits, one word per row), the Winograd transform's per-tile words, or a row bound carried through the GEMM in
+# between (rowmax(g) ||W||_1, _FrozenMlp).  2 = two bf16 terms (16 significant bits, no scales; rounds 3's default: the
+# attack only uses sign(gradient), attacker.py:396), 3 = three bf16 terms (exact split, six products).
+GEMM_TERMS_BWD = int(os.environ.get("SEA_GEMM_TERMS_BWD", "22"))
 GEMM_MIN_ROWS = 1024   # below, a 128-row tile grid cannot fill the chip: hipBLASLt's split-K kernels win
 _TERMS_OVERRIDE = [None]
 
@@ -251,8 +253,8 @@ def _terms():
 
 def _bwd_terms(fwd_terms):
     """terms of the input-gradient products of a Function whose forward ran with ``fwd_terms``"""
-    if fwd_terms == 22:                      # fp16 x 2 forward: the input gradient keeps the range-safe bf16 terms
-        return GEMM_TERMS_BWD if GEMM_TERMS_BWD in (2, 3) else 3
+    if fwd_terms == 22:                      # fp16 x 2 forward: fp16 x 2 with per-row scales, or the scale-free bf16 terms
+        return GEMM_TERMS_BWD if GEMM_TERMS_BWD in (2, 3, 22) else 3
     return min(fwd_terms, GEMM_TERMS_BWD) if fwd_terms in (2, 3) and GEMM_TERMS_BWD in (2, 3) else fwd_terms
 
 
@@ -287,10 +289,12 @@ def _packed(w, cache, name, trans, terms):
     return cache[name]
 
 
-def _frozen_mm(x2d, w, cache, name, trans=False, bias=None, relu=False, terms=None, amax=None, out_amax=None, groups=1):
+def _frozen_mm(x2d, w, cache, name, trans=False, bias=None, relu=False, terms=None, amax=None, out_amax=None, groups=1,
+               row_amax=False):
     """act(x2d @ W^T + bias) for a FROZEN weight: w is (N, K), or (K, N) with ``trans``.  ``groups`` = number of images
     the rows of x2d belong to (image-major): without a supplied ``amax`` the fp16 x 2 mode scales every image by its own
-    maximum, so that an image's result does not depend on its batch partners."""
+    maximum, so that an image's result does not depend on its batch partners; ``row_amax``: every ROW by its own (the
+    input-gradient products: a gradient's rows span many orders of magnitude)."""
     K = w.shape[0] if trans else w.shape[1]
     terms = _terms() if terms is None else terms
     if _split_ok(x2d, K, terms):
@@ -298,7 +302,7 @@ def _frozen_mm(x2d, w, cache, name, trans=False, bias=None, relu=False, terms=No
         if terms != 22:
             amax = out_amax = None
         return N.gemm_split(x2d, _packed(w, cache, name, trans, terms), bias=bias, relu=relu, amax=amax, out_amax=out_amax,
-                            groups=groups)
+                            groups=groups, row_amax=row_amax)
     wt = w if trans else w.t()
     y = torch.addmm(bias, x2d, wt) if bias is not None else x2d @ wt
     return torch.relu_(y) if relu else y
@@ -333,6 +337,17 @@ def _linear_bound_word(in_word, w, b, cache):
     return cache["lin_bound"]
 
 
+def _l1_bound(w, cache, dim):
+    """max over the other dim of sum_dim |w| as a Python float, rounded up (one device sync per weight, cached until the
+    weight changes).  For w of shape (N, K): dim = 0 bounds the input-gradient product u = g w row by row,
+    |u[r][k]| = |sum_n g[r][n] w[n][k]| <= rowmax(g[r]) * max_k sum_n |w[n][k]|; dim = 1 bounds the forward product x w^T."""
+    key = (_tkey(w), dim)
+    if cache.get("l1_key") != key:
+        with torch.no_grad():
+            cache.update(l1_key=key, l1=float(w.detach().abs().sum(dim).max().item()) * (1.0 + 1e-6))
+    return cache["l1"]
+
+
 class _FrozenLinear(torch.autograd.Function):
     """F.linear(x, w, b) for frozen (w, b), input gradient only: both directions through ``_frozen_mm``."""
 
@@ -350,7 +365,7 @@ class _FrozenLinear(torch.autograd.Function):
         g2 = gy.reshape(-1, gy.shape[-1])
         if not g2.is_contiguous():
             g2 = g2.contiguous()
-        return (_frozen_mm(g2, ctx.w, ctx.cache, "lin_bwd", trans=True, terms=_bwd_terms(ctx.terms),
+        return (_frozen_mm(g2, ctx.w, ctx.cache, "lin_bwd", trans=True, terms=_bwd_terms(ctx.terms), row_amax=True,
                            groups=ctx.shape[0] if len(ctx.shape) > 2 else 1).view(ctx.shape), None, None, None, None, None)
 
 
@@ -445,12 +460,21 @@ class _FrozenMlp(torch.autograd.Function):
             g2 = g2.contiguous()
         nb = ctx.shape[0] if len(ctx.shape) > 2 else 1
         p2, p1 = (_packed(ctx.w[1], ctx.caches[1], "lin_bwd", True, terms), _packed(ctx.w[0], ctx.caches[0], "lin_bwd", True, terms))
-        if ctx.fuse & 2:
-            gx = N.gemm_split(N.gemm_split(g2, p2, gelu_grad_of=t, groups=nb), p1, groups=nb)
-        elif ctx.fuse & 8 and terms in (2, 22) and -(-ctx.w[0].shape[1] // 128) <= FUSE_PROLOGUE_MAX_NBLOCKS:
-            gx = N.gemm_split(N.gemm_split(g2, p2, groups=nb), p1, a_gelu_grad_of=t, groups=nb)
+        # fp16 x 2: ONE pass for the per-row maxima of g; the second product's operand u = g W2 (times GELU' <= 1.13) is
+        # bounded row by row through the first: |u[r][n]| <= rowmax(g[r]) * max_n ||W2[n]||_1  (no pass over the 4C-wide u)
+        rows = {}
+        if terms == 22:
+            words, _ = N._amax_words(g2.unsqueeze(0), g2.shape[0], g2.shape[1], 1, 0, nb, per_row=True)
+            rows = dict(amax=words, amax_rows=1)
+            mul = dict(amax_mul=_l1_bound(ctx.w[1], ctx.caches[1], dim=0) * 1.13, **rows)
         else:
-            gx = N.gemm_split(torch.ops.aten.gelu_backward(N.gemm_split(g2, p2, groups=nb), t), p1, groups=nb)
+            mul = {}
+        if ctx.fuse & 2:
+            gx = N.gemm_split(N.gemm_split(g2, p2, gelu_grad_of=t, groups=nb, **rows), p1, groups=nb, **mul)
+        elif ctx.fuse & 8 and terms in (2, 22) and -(-ctx.w[0].shape[1] // 128) <= FUSE_PROLOGUE_MAX_NBLOCKS:
+            gx = N.gemm_split(N.gemm_split(g2, p2, groups=nb, **rows), p1, a_gelu_grad_of=t, groups=nb, **mul)
+        else:
+            gx = N.gemm_split(torch.ops.aten.gelu_backward(N.gemm_split(g2, p2, groups=nb, **rows), t), p1, groups=nb, **mul)
         return gx.view(ctx.shape), None, None, None, None, (g if ctx.has_res else None), None, None, None
 
 
@@ -641,7 +665,7 @@ class _PatchConv2x2(torch.autograd.Function):
         B, C, H, W = ctx.shape
         g = gy.permute(0, 2, 3, 1).reshape(-1, gy.shape[1])
         rows = _frozen_mm(g if g.is_contiguous() else g.contiguous(), ctx.wr, ctx.cache, "patch_bwd", trans=True,
-                          terms=_bwd_terms(ctx.terms), groups=B).float()
+                          terms=_bwd_terms(ctx.terms), groups=B, row_amax=True).float()
         if C % 4 == 0 and rows.is_contiguous():
             from .. import _native as N
             gp = N.unpatch2x2(rows, B, H, W)
@@ -812,10 +836,11 @@ class _PointwiseRelu(torch.autograd.Function):
                 and _split_ok(gy, ctx.w.shape[0], terms)):
             # the ReLU gate is applied to the A tile of the input-gradient GEMM while it is staged: no masked copy of gy
             from .. import _native as N
-            return (N.gemm_split(gy, _packed(ctx.w, ctx.cache, "pw_bwd", True, terms), a_relu_gate=y, groups=ctx.groups), None,
-                    None, None, None)
+            return (N.gemm_split(gy, _packed(ctx.w, ctx.cache, "pw_bwd", True, terms), a_relu_gate=y, groups=ctx.groups,
+                                 row_amax=True), None, None, None, None)
         g = torch.where(y > 0, gy, torch.zeros((), dtype=gy.dtype, device=gy.device))
-        return (_frozen_mm(g, ctx.w, ctx.cache, "pw_bwd", trans=True, terms=terms, groups=ctx.groups), None, None, None, None)
+        return (_frozen_mm(g, ctx.w, ctx.cache, "pw_bwd", trans=True, terms=terms, groups=ctx.groups, row_amax=True), None, None,
+                None, None)
 
 
 class ConvModule(nn.Module):
@@ -1063,7 +1088,7 @@ class _FpnBottleneck(torch.autograd.Function):
                 h, w = shapes[i][2:]
                 dG = N.tap_gather_backward(gz, (h, w))
                 grads[i] = _frozen_mm(dG.view(B * h * w, -1), cache["fpn_lo"][j], cache, f"fpn_lo_bwd{j}", trans=True,
-                                      terms=_bwd_terms(ctx.terms), groups=B).view(B, h, w, chans[i]).permute(0, 3, 1, 2)
+                                      terms=_bwd_terms(ctx.terms), groups=B, row_amax=True).view(B, h, w, chans[i]).permute(0, 3, 1, 2)
         return (None, None, None, None, None, *grads)
 
 

@@ -12,6 +12,7 @@ masks, bilinear x16 back to the padded size, crop.
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -43,6 +44,7 @@ class LayerNorm(nn.LayerNorm):
 
 
 USE_HIP_ATTENTION = True
+ATTN_TERMS_BWD = int(os.environ.get("SEA_ATTN_TERMS_BWD", "3"))
 
 
 class _AttentionHip(torch.autograd.Function):
@@ -63,9 +65,9 @@ class _AttentionHip(torch.autograd.Function):
     def backward(ctx, g):
         from .. import _native as N
         qkv, out, lse = ctx.saved_tensors
-        # weights trained through this backward: three bf16 terms per operand (fp32 level); an attack only consumes the
-        # sign of the input gradient: the library default (two terms)
-        return N.attention_qkv_backward(qkv, out, lse, g, ctx.scale, terms=3 if ctx.train else None), None, None
+        # three bf16 terms per operand = the fp32 operands exactly (training AND attack: the evaluation is fp32-equivalent
+        # like the reference's); SEA_ATTN_TERMS_BWD=2 selects round 3's two-term mode (an attack only consumes the sign)
+        return N.attention_qkv_backward(qkv, out, lse, g, ctx.scale, terms=3 if ctx.train else ATTN_TERMS_BWD), None, None
 
 
 class Attention(nn.Module):

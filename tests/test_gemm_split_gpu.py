@@ -304,3 +304,73 @@ def test_fp16x2_per_image_scales_make_rows_independent_of_their_batch(N):
     assert torch.equal(words.view(torch.float32), torch.stack([wide[i:i + 250, 16:80].abs().max() for i in range(0, 1000, 250)]))
     with pytest.raises(N.SeaNativeError):
         N.gemm_split(a0, P, amax=w_img, amax_rows=1)                 # too few words
+
+
+@pytest.mark.parametrize("M,K,lda", [(131072, 96, 96), (5000, 16, 16), (777, 192, 200), (4096, 384, 384), (1031, 512, 512),
+                                     (2048, 4608, 4608), (300, 768, 1024)])
+def test_row_maxima_words_are_exact(N, M, K, lda):
+    """sea_absmax_bits(rows_per_word = 1): one word per row = the float bits of max|row|, exactly (incl. -0, denormals, a row
+    of zeros, a strided operand); every word has one writer, so an un-initialised output buffer is fine"""
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    buf = torch.randn(M, lda, generator=g, device="cuda") * torch.exp(8 * torch.randn(M, 1, generator=g, device="cuda"))
+    buf[3] = 0
+    buf[5, :K] = 1e-41
+    A = buf[:, :K]
+    words, rows = N._amax_words(A.unsqueeze(0), M, K, 1, 0, 1, per_row=True)
+    assert rows == 1 and words.shape == (M,)
+    assert torch.equal(words, A.abs().amax(1).view(torch.int32))
+
+
+def test_fp16x2_per_row_scales_keep_every_gradient_row_at_fp32_level(N):
+    """The input-gradient products (round 4: fp16 x 2 by default).  A gradient's rows (pixels) span many orders of magnitude:
+    with ONE scale per image the small rows fall into fp16's sub-normal range and lose their bits; with one scale per row
+    (row_amax) every row is as accurate, relative to its OWN magnitude, as the fp32 GEMM"""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    M, K, Nn = 8192, 384, 1536
+    mag = torch.exp2(torch.randint(-60, 10, (M, 1), generator=g, device="cuda").float())      # 2^-60 .. 2^10 per row
+    A = torch.randn(M, K, generator=g, device="cuda") * mag
+    W = torch.randn(Nn, K, generator=g, device="cuda") / K ** 0.5
+    ref = _ref(A, W)
+    row_scale = ref.abs().amax(1, keepdim=True)
+
+    def row_err(out):
+        return ((out.double() - ref).abs() / row_scale).amax().item()
+
+    Wp = N.gemm_split_pack(W, terms=22)
+    e_lib = row_err(A @ W.t())
+    e_row = row_err(N.gemm_split(A, Wp, row_amax=True))
+    e_img = row_err(N.gemm_split(A, Wp, groups=8))
+    e_b2 = row_err(N.gemm_split(A, N.gemm_split_pack(W, terms=2)))
+    print(f"max row-relative error: hipBLASLt fp32 {e_lib:.2e}   fp16x2 per-row scales {e_row:.2e}   "
+          f"fp16x2 per-image scales {e_img:.2e}   bf16x2 {e_b2:.2e}")
+    assert e_row <= max(4.0 * e_lib, 2e-6), (e_row, e_lib)
+    assert e_img > 1e-3            # what per-row scales are for
+    # the result of a row does not depend on the other rows of the batch
+    sub = A[1000:1256].contiguous()
+    assert torch.equal(N.gemm_split(sub, Wp, row_amax=True), N.gemm_split(A, Wp, row_amax=True)[1000:1256])
+
+
+def test_fp16x2_row_bound_carried_through_a_gemm(N):
+    """amax_mul: the second input-gradient product of an MLP takes its row scales from the FIRST product's operand,
+    |(g W2)[r]| <= rowmax(g[r]) * max_k sum_n |W2[n][k]| -- no pass over the 4C-wide intermediate.  The bound is loose by
+    the ratio of the l1 norm to the realised maximum (3-30x), which fp16 x 2 does not notice"""
+    from semseg.models import convnext_upernet as M
+    g = torch.Generator(device="cuda").manual_seed(12)
+    R, C = 4096, 192
+    W2 = torch.randn(C, 4 * C, generator=g, device="cuda") * 0.05          # Linear(4C -> C).weight
+    W1 = torch.randn(4 * C, C, generator=g, device="cuda") * 0.05          # Linear(C -> 4C).weight
+    gy = torch.randn(R, C, generator=g, device="cuda") * torch.exp2(torch.randint(-40, 4, (R, 1), generator=g, device="cuda").float())
+    t = torch.randn(R, 4 * C, generator=g, device="cuda")
+    words, _ = N._amax_words(gy.unsqueeze(0), R, C, 1, 0, 1, per_row=True)
+    mul = M._l1_bound(W2, {}, dim=0) * 1.13
+    u = N.gemm_split(gy, N.gemm_split_pack(W2, trans=True, terms=22), amax=words, amax_rows=1)
+    loose = (words.view(torch.float32) * mul) / (u * torch.ops.aten.gelu_backward(torch.ones_like(u), t)).abs().amax(1)
+    assert loose.min() >= 1.0, loose.min()                # it IS a bound
+    print(f"row bound / realised row maximum: median {loose.median():.1f}, max {loose.max():.1f}")
+    got = N.gemm_split(u, N.gemm_split_pack(W1, trans=True, terms=22), a_gelu_grad_of=t, amax=words, amax_rows=1, amax_mul=mul)
+    ref = (u.double() * torch.ops.aten.gelu_backward(torch.ones_like(u), t).double()) @ W1.double()
+    lib = (u * torch.ops.aten.gelu_backward(torch.ones_like(u), t)) @ W1
+    rs = ref.abs().amax(1, keepdim=True)
+    e_got, e_lib = ((got.double() - ref).abs() / rs).amax().item(), ((lib.double() - ref).abs() / rs).amax().item()
+    print(f"max row-relative error: hipBLASLt fp32 {e_lib:.2e}   fp16x2 with carried row bounds {e_got:.2e}")
+    assert e_got <= max(4.0 * e_lib, 2e-6), (e_got, e_lib)

@@ -253,8 +253,9 @@ def test_gemm_epilogue_struct_matches_the_header(native):
         if not decl:
             continue
         ctype, names = decl.rsplit(" ", 1)[0], decl
-        m = re.match(r"(const float\*|float\*|int64_t|int)\s+(.*)", decl)
+        m = re.match(r"(const float\*|float\*|int64_t|int|float)\s+(.*)", decl)
         assert m, decl
-        kind = {"const float*": ctypes.c_void_p, "float*": ctypes.c_void_p, "int64_t": ctypes.c_int64, "int": ctypes.c_int}[m.group(1)]
+        kind = {"const float*": ctypes.c_void_p, "float*": ctypes.c_void_p, "int64_t": ctypes.c_int64, "int": ctypes.c_int,
+                "float": ctypes.c_float}[m.group(1)]
         fields += [(n.strip(), kind) for n in m.group(2).split(",")]
     assert [(n, t) for n, t in native._GemmEpilogue._fields_] == fields

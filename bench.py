@@ -12,8 +12,14 @@ world size RCCL reported after an all-reduce over all ranks, never the flag.
 One "step" = one APGD loop iteration over one batch of B=8 synthetic 512x512 images per GPU:
 L-inf step kernel (K1) + model forward (PyTorch-ROCm) + fused loss/gradient kernel (K2) + model
 input-gradient backward + device-side bookkeeping kernels (K4/K7).  Inputs are resident in HBM before
-the timed region.  fp32 end to end, like the reference's evaluation.  Images shard across ranks with
-no collective in the loop (weak scaling).
+the timed region.  Arithmetic: fp32 storage and fp32 accumulation everywhere; the frozen-weight GEMMs of the model
+(forward AND input gradient) run on the 16-bit matrix cores with every fp32 operand split into two fp16 terms
+(22 significant bits, power-of-two scales per row; measured error against float64 <= the fp32 GEMM's own,
+tests/test_gemm_split_gpu.py), so the evaluation is fp32-equivalent like the reference's; `dtype` in the JSON line
+states the mode that actually ran (SEA_GEMM_TERMS / SEA_GEMM_TERMS_BWD select others).  Images shard across ranks
+with no collective in the loop (weak scaling).  After the timed window `--sustain` further steps (default 300 = a
+full SEA attack's length) are timed the same way and reported as `config.sustained_ms_per_step`: the chip lowers
+its clock under sustained matrix load, which a 20-step window does not see.
 """
 import argparse
 import json
@@ -121,6 +127,11 @@ def k2_cold_ms(N, run, logits_shape, C, HW):
     return best
 
 
+def _mode_name(terms):
+    return {22: "fp16x2 (22 significant bits per operand, 3 MFMA products)", 3: "bf16x3 (24 bits, 6 products)",
+            2: "bf16x2 (16 bits, 3 products)"}.get(terms, "hipBLASLt fp32")
+
+
 def make_model(backbone, C):
     """UperNet-ConvNeXt (BASELINE configs 1, 2, 4, 5) or Segmenter ViT (config 3: --backbone vit_small_patch16_224)."""
     if backbone.startswith("vit_"):
@@ -183,6 +194,8 @@ def main():
     ap.add_argument("--loss", default="mask-ce-bal")
     ap.add_argument("--eps", type=float, default=8.0, help="radius in 1/255 (SEA stage-1 radius for eps=4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sustain", type=int, default=300,
+                    help="steps timed AFTER the K-step window for config.sustained_ms_per_step (0 = skip)")
     ap.add_argument("--fuse-upsample", action="store_true",
                     help="force K2u (loss fused with the model's final bilinear upsample); default: the library's "
                          "heuristic (unfused unless the full-resolution logits + gradient exceed 24 GB)")
@@ -213,7 +226,7 @@ def main():
     torch.backends.cudnn.benchmark = True  # MIOpen find mode: pick the fastest conv algorithms
 
     from semseg import _native as N, attacker as A
-    from semseg.models.convnext_upernet import GEMM_TERMS, GEMM_TERMS_BWD
+    from semseg.models.convnext_upernet import GEMM_TERMS, _bwd_terms
     from semseg.utils.utils import ADE_WTS, VOC_WTS
     N.lib()
     B, C, K, W = args.batch, args.classes, args.steps, args.warmup
@@ -223,7 +236,8 @@ def main():
 
     # default: the model's own upsample + the HBM-bound K2 (the kernel SURVEY 8d prices); --fuse-upsample
     # switches to K2u (no full-resolution logits in HBM; 0.8 ms/step slower on Segmenter x16, C=151)
-    run = A.ApgdRun(model, x, y, eps, W + K + 1, args.loss, "ce-avg", True, C, weights, x.clone(),
+    S = max(args.sustain, 0)
+    run = A.ApgdRun(model, x, y, eps, W + K + S + 1, args.loss, "ce-avg", True, C, weights, x.clone(),
                     fuse_upsample=True if args.fuse_upsample else (False if args.no_fuse_upsample else None))
     run.start()
     for i in range(W):
@@ -257,6 +271,24 @@ def main():
         per_rank = [{"rank": r, "ms_per_step": float(v[0]) * 1e3 / K, "host_enqueue_ms_per_step": float(v[1]) * 1e3 / K}
                     for r, v in enumerate(allr)]
         dt = max(float(v[0]) for v in allr)
+
+    # sustained rate: S more steps of the same loop, same barriers, max over ranks (a SEA stage is 90-120 steps, an attack 300)
+    sustained = None
+    if S > 0:
+        k2_events, run.k2_events = run.k2_events, None
+        gc.disable()
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(W + K, W + K + S):
+            run.step(i)
+        barrier()
+        sustained = (time.perf_counter() - t1) * 1e3 / S
+        gc.enable()
+        run.k2_events = k2_events
+        if world > 1:
+            mine = torch.tensor([sustained], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(mine, op=dist.ReduceOp.MAX)
+            sustained = float(mine.item())
 
     k2_ms = (sum(a.elapsed_time(b) for a, b in run.k2_events) / max(len(run.k2_events), 1)) if run.k2_events else float("nan")
     kname = ("loss_upsampled_kernel (K2u)" if run.fused else
@@ -300,9 +332,8 @@ def main():
             "ms_per_step": dt * 1e3 / K,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32 (frozen-weight GEMMs on the 16-bit matrix cores by operand splitting: "
-                      + ("fp16x2 = 22 significant bits" if GEMM_TERMS == 22 else f"bf16x{GEMM_TERMS}") + " forward, bf16x"
-                      + str(GEMM_TERMS_BWD if GEMM_TERMS == 22 else min(GEMM_TERMS, GEMM_TERMS_BWD))
-                      + " input gradient; fp32 accumulate)") if GEMM_TERMS in (2, 3, 22) else "f32",
+                      + _mode_name(GEMM_TERMS) + " forward, " + _mode_name(_bwd_terms(GEMM_TERMS))
+                      + " input gradient; fp32 storage and accumulate)") if GEMM_TERMS in (2, 3, 22) else "f32",
             "data": "synthetic",
             "config": {
                 "workload": f"{'Segmenter-' if args.backbone.startswith('vit_') else 'UperNet-'}{args.backbone} C={C} "
@@ -311,11 +342,11 @@ def main():
                 "batch_per_gpu": B, "global_batch": world * B, "sharding": f"images x{world}, no in-loop collective",
                 "batch_steps_per_s": world * K / dt, "host_enqueue_ms_per_step": t_enqueue * 1e3 / K,
                 "hip_graph": bool(run.graphs is not None),
-                "gemm": ("sea_gemm_split: forward products " + ("fp16x2 split MFMA (22 significant bits per operand, 3 products)"
-                         if GEMM_TERMS == 22 else f"bf16x{GEMM_TERMS} split MFMA") + ", input-gradient products bf16x"
-                         + str(GEMM_TERMS_BWD if GEMM_TERMS == 22 else min(GEMM_TERMS, GEMM_TERMS_BWD)) + ", fp32 accumulate"
-                         + "; per-row power-of-two activation scales, split-K for small tile grids, GELU / GELU' / ReLU-gate"
-                         + " prologues")
+                "sustained_ms_per_step": sustained, "sustained_steps": S,
+                "gemm": ("sea_gemm_split: forward products " + _mode_name(GEMM_TERMS) + ", input-gradient products "
+                         + _mode_name(_bwd_terms(GEMM_TERMS)) + ", fp32 accumulate; power-of-two scales per row (forward: analytic "
+                         + "bounds / Winograd tile maxima; gradient: exact row maxima / Winograd tile maxima / row bounds carried "
+                         + "through the MLP), split-K for small tile grids, GELU / GELU' / ReLU-gate prologues")
                 if GEMM_TERMS in (2, 3, 22) else "hipBLASLt fp32",
                 **({"per_rank": per_rank} if per_rank else {}),
             },

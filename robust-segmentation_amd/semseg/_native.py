@@ -722,10 +722,10 @@ def gemm_split_pack(W, trans: bool = False, terms: int = 3) -> PackedWeight:
 
 
 class AmaxPool:
-    """Zero-initialised 4-byte device words that producers max-accumulate |x| bits into (atomicMax needs a zeroed word)
-    and fp16 x 2 GEMMs read their activation scale from.  One small tensor per device, re-zeroed with ONE fill per model
-    forward (``reset``) instead of one memset per GEMM; words are handed out in call order, so a HIP-graph replay of the
-    same forward touches the same words."""
+    """Zero-initialised 4-byte device words for the ``out_amax`` output of the fp16 x 2 GEMMs (atomicMax needs a zeroed
+    word): a helper for callers of that ABI feature and its tests.  The shipped models do not use it (their scales come
+    from analytic bounds, the Winograd transform and per-row maxima, none of which needs a zeroed word), so no model
+    forward resets it."""
     _pools = {}
     SIZE = 1024
 
@@ -781,13 +781,21 @@ def _ksplit(M, N, K):
 
 
 def _ksplit_workspace(device, numel):
-    """(splits, M, N) partial products: one buffer per device and stream, grown on demand (a HIP-graph capture sees the
-    buffer of its capture stream, allocated by the eager iteration that runs on that stream first)"""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    """(splits, M, N) partial products: ONE buffer per device, grown on demand.  A product and its reduce pass run back to
+    back on one stream, and every consumer of this module orders its streams (ApgdRun: wait_stream both ways around the
+    iteration it runs on its capture stream), so one buffer serves them all; keyed by stream it leaked one ~50 MB buffer per
+    pooled stream handle.  A captured HIP graph bakes the buffer's address in: ApgdRun pins the tensor for the lifetime
+    of its graphs (``ksplit_workspace_pin``), so a later, larger product that replaces the entry cannot free it."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
     ws = _ksplit_ws.get(key)
     if ws is None or ws.numel() < numel:
         ws = _ksplit_ws[key] = torch.empty(numel, dtype=torch.float32, device=device)
     return ws[:numel]
+
+
+def ksplit_workspace_pin(device):
+    """the current split-K workspace tensor of ``device`` (or None): hold the reference while a captured graph may replay"""
+    return _ksplit_ws.get(device.index if device.index is not None else torch.cuda.current_device())
 
 
 class _GemmEpilogue(C.Structure):       # SeaGemmEpilogue of include/sea_hip.h

@@ -426,25 +426,56 @@ class ApgdRun:
     def _graph_ready(self):
         return self.graphs is not None
 
+    def _graph_failed(self, exc):
+        """A model whose forward / backward cannot be captured (a host sync such as .item(), a library that allocates or
+        JIT-compiles on first use of a shape, ...) keeps working: the run continues with the eager loop, which is the same
+        kernels in the same order.  Reported once per run on stderr."""
+        import sys
+        self.use_graph, self.graphs = False, None
+        self._g_xin = self._g_logits = None
+        # torch.cuda.graph.__exit__ does not leave its stream context when capture_end() itself raises (an invalidated
+        # capture): put the caller's stream back
+        torch.cuda.set_stream(self._caller_stream)
+        print(f"[sea] HIP-graph capture of the attack step failed ({type(exc).__name__}: {str(exc).splitlines()[0][:160]}); "
+              "continuing with the eager loop", file=sys.stderr)
+        torch.cuda.synchronize()
+
     def _capture(self, i: int):
+        """captures the two graphs AND performs iteration i; falls back to the eager loop when a capture fails"""
         dev = self.x.device
+        self._caller_stream = torch.cuda.current_stream()
         self.it_dev = torch.full((1,), i, dtype=torch.int32, device=dev)
         tab = [self.cps.get(k, 0) for k in range(max(self.n_iter, 1))]
         self.cp_dev = torch.tensor(tab, dtype=torch.int32, device=dev)
         ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga, stream=self._gs):
-            N.apgd_linf_step_graph(self.x, self.x_adv, self.x_old, self.grad, self.st.step, self.eps, self.it_dev)
-            self._g_xin, self._g_logits = _forward_logits(self.model, self.x_adv, True, self.fused)
+        try:
+            with torch.cuda.graph(ga, stream=self._gs):
+                N.apgd_linf_step_graph(self.x, self.x_adv, self.x_old, self.grad, self.st.step, self.eps, self.it_dev)
+                self._g_xin, self._g_logits = _forward_logits(self.model, self.x_adv, True, self.fused)
+        except Exception as exc:   # nothing of iteration i has run yet (a capture executes nothing)
+            self._graph_failed(exc)
+            return self._step_eager(i)
         ga.replay()
         r = self._loss(self._g_logits, True)          # eager, and it defines the (persistent) K2 output buffers
-        with torch.cuda.graph(gb, pool=ga.pool(), stream=self._gs):
-            g = _input_grad(self._g_logits, self._g_xin, r["dlogits"])
-            self.grad.copy_(g)                           # the gradient buffer keeps its address (K1 / K4 read it)
-            N.apgd_track_graph(r, self.n_ignored, self.HW, self.it_dev, self.cp_dev, self.n_iter, self.early_stop, self.st)
+        try:
+            with torch.cuda.graph(gb, pool=ga.pool(), stream=self._gs):
+                g = _input_grad(self._g_logits, self._g_xin, r["dlogits"])
+                self.grad.copy_(g)                           # the gradient buffer keeps its address (K1 / K4 read it)
+                N.apgd_track_graph(r, self.n_ignored, self.HW, self.it_dev, self.cp_dev, self.n_iter, self.early_stop, self.st)
+                N.select_copy(self.st.flags, self.x_adv, self.grad, self.x_best, self.grad_best, self.x_best_adv, self.pred,
+                              self.pred_best)
+        except Exception as exc:   # K1 + forward + K2 of iteration i are done (graph A replayed): finish it eagerly
+            logits, x_in = self._g_logits, self._g_xin
+            self._graph_failed(exc)
+            self.grad.copy_(_input_grad(logits, x_in, r["dlogits"]))
+            N.apgd_track(r, self.n_ignored, self.HW, i, self.n_iter, self.cps.get(i, 0), self.early_stop, False, self.st)
             N.select_copy(self.st.flags, self.x_adv, self.grad, self.x_best, self.grad_best, self.x_best_adv, self.pred,
                           self.pred_best)
+            return
         gb.replay()
         self.graphs = (ga, gb)
+        # the graphs bake in the address of the split-K workspace the model's GEMMs used: keep it alive while they may replay
+        self._ws_pin = N.ksplit_workspace_pin(dev)
 
     def _step_graph(self, i: int):
         if self.graphs is None:
@@ -459,6 +490,7 @@ class ApgdRun:
         B=8, 512x512; an evaluation creates three runs per batch and attack)"""
         self.graphs = None
         self._g_xin = self._g_logits = None
+        self._ws_pin = None
 
     def result(self):
         return self.x_best, self.st.acc, self.st.loss_best, self.x_best_adv

@@ -1238,20 +1238,12 @@ class UperNetForSemanticSegmentation(nn.Module):
                 return self.decode_head(feats)
         return self.decode_head(feats)
 
-    @staticmethod
-    def _reset_amax_pool(t):
-        if t.is_cuda and GEMM_TERMS == 22:
-            from .. import _native as N
-            N.AmaxPool.get(t.device).reset()
-
     def forward_lowres(self, input):
         """(logits at 1/4 resolution, output size): semseg.attacker fuses the final bilinear upsample
         into its loss kernel (K2u) when a model offers this hook."""
-        self._reset_amax_pool(input)
         return self._head_logits(self.backbone(input)), tuple(input.shape[2:])
 
     def forward(self, input, lbl=None):
-        self._reset_amax_pool(input)
         feats = self.backbone(input)
         logits = _up(self._head_logits(feats).contiguous(), input.shape[2:])  # NCHW logits for K2
         loss = None

@@ -297,7 +297,6 @@ class SegMenter(nn.Module):
         H0, W0 = im.shape[2:]
         if H0 % self.patch_size or W0 % self.patch_size:
             return None
-        _cu.UperNetForSemanticSegmentation._reset_amax_pool(im)
         x = self.encoder(im, pre_neck=True)
         x = x[:, 0 if "SAM" in self.backbone else 1 + int(self.encoder.distilled):]
         return self.decoder(x, (H0, W0)).contiguous(), (H0, W0)
@@ -308,7 +307,6 @@ class SegMenter(nn.Module):
         if ph or pw:
             im = F.pad(im, (0, pw, 0, ph), value=0)
         H, W = im.shape[2:]
-        _cu.UperNetForSemanticSegmentation._reset_amax_pool(im)
         x = self.encoder(im, pre_neck=True)
         x = x[:, 0 if "SAM" in self.backbone else 1 + int(self.encoder.distilled):]
         masks = _up(self.decoder(x, (H, W)).contiguous(), (H, W))  # bilinear x16 (libsea_hip M2 on HIP tensors)

@@ -219,3 +219,61 @@ def test_hip_graph_replay_is_bitwise_the_eager_loop(loss):
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
     assert (outs[0][3] - x).abs().max() <= 8.0 / 255 + 1e-6
+
+
+@pytest.mark.parametrize("where", ["forward", "backward"])
+def test_hip_graph_capture_failure_falls_back_to_the_eager_loop(where, capfd):
+    """A model that cannot be captured (a host synchronisation inside its forward, or inside its backward) must keep
+    working: ApgdRun notices the failed capture, reports it once and continues eagerly with the same kernels -- the
+    result equals the run with graphs switched off, bit for bit, and later graph users are unaffected."""
+    from oracle.tiny_models import make_labels
+    from semseg import attacker as A
+
+    class _Sync(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, in_fwd):
+            ctx.in_fwd = in_fwd
+            if in_fwd:
+                float(x.flatten()[0].item())          # host sync: illegal during capture
+            return x.view_as(x)
+
+        @staticmethod
+        def backward(ctx, g):
+            if not ctx.in_fwd:
+                float(g.flatten()[0].item())
+            return g, None
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.net = PointwiseNet(21, seed=3)      # explicit element-wise ops: bitwise reproducible on any box
+
+        def forward(self, x):
+            return self.net(_Sync.apply(x, where == "forward"))
+
+    model = Net().eval().cuda()
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(2, 3, 32, 32, generator=g)
+    y = make_labels(model.net.cpu(), x, ignore_frac=0.03, flip_frac=0.1, seed=2).cuda()
+    model.cuda()
+    x = x.cuda()
+    w = torch.rand(21, generator=g).cuda()
+    outs = []
+    for graph in (False, True):
+        old, A.USE_HIP_GRAPH = A.USE_HIP_GRAPH, graph
+        try:
+            outs.append(A.apgd_train(model, x, y, "Linf", 8.0 / 255, n_iter=20, loss="mask-ce-bal", early_stop=True,
+                                     track_loss="ce-avg", num_classes=21, weights=w, return_pred=True))
+        finally:
+            A.USE_HIP_GRAPH = old
+    assert "continuing with the eager loop" in capfd.readouterr().err
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    assert torch.cuda.current_stream() == torch.cuda.default_stream()
+    # a capturable model still gets its graphs afterwards
+    run = A.ApgdRun(model.net, x, y, 8.0 / 255, 20, "mask-ce-bal", "ce-avg", True, 21, w, x.clone())
+    run.start()
+    for i in range(4):
+        run.step(i)
+    assert run.graphs is not None
+    run.release_graphs()

@@ -84,3 +84,71 @@ def replay_pgd(g, x):
     x_adv = (x + delta).clamp(0.0, 1.0)
     assert torch.equal(x_adv.flatten()[g["sample_idx"].long()], g["x_adv_samples"])
     return xs, deltas, x_adv
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# exact controller tests (tests/test_controller_exact_gpu.py): the product's attack with the reference's gradient signs
+# ---------------------------------------------------------------------------------------------------------------------
+def checksum(x):
+    """per-image sum of the float32 bit patterns as int64 (oracle/gen_controller_goldens.py:checksum)"""
+    return x.contiguous().view(torch.int32).to(torch.int64).flatten(1).sum(1)
+
+
+class _InjectSign(torch.autograd.Function):
+    """identity whose backward DISCARDS the incoming gradient and returns the reference's sign plane of this evaluation"""
+
+    @staticmethod
+    def forward(ctx, x, signs, idx):
+        ctx.save_for_backward(signs, idx)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        signs, idx = ctx.saved_tensors
+        return signs.index_select(0, idx)[0].to(g.dtype), None, None
+
+
+class SignInjector(torch.nn.Module):
+    """Thin wrapper around the attacked model for the exact controller tests.  Every forward (a) stores the per-image
+    checksum of the iterate it was given in row `evaluation index` of ``chk`` and (b) makes the gradient that flows back to
+    the iterate the REFERENCE's sign(g) of that evaluation (``signs``: (E, *x.shape) int8 on the device, rows without a
+    gradient unused).  The evaluation counter lives in device memory and is advanced by the forward itself, so the wrapper
+    behaves the same inside the product's captured HIP graphs (where this Python code runs once, at capture) as in its
+    eager iterations.  The model's own forward / backward still run: losses, accuracies and all controller decisions are
+    the product's."""
+
+    def __init__(self, model, signs):
+        super().__init__()
+        self.model, self.signs = model, signs
+        self.E = signs.shape[0]
+        dev = signs.device
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.chk = torch.zeros(self.E + 1, signs.shape[1], dtype=torch.int64, device=dev)   # row E: overflow sink
+
+    def forward(self, x):
+        with torch.no_grad():
+            idx = self.counter.clamp(max=self.E)
+            self.counter += 1
+            self.chk.index_copy_(0, idx, checksum(x.detach()).unsqueeze(0))
+        if torch.is_grad_enabled() and x.requires_grad:
+            x = _InjectSign.apply(x, self.signs, idx.clamp(max=self.E - 1))
+        return self.model(x)
+
+
+def sign_planes(g, shape, device):
+    """(E, *shape) int8 sign planes of a g13 / t1 fixture (zeros where the evaluation took no gradient)"""
+    E = int(g["n_evals"])
+    n = int(np.prod(shape))
+    out = torch.zeros(E, *shape, dtype=torch.int8)
+    for e in range(E):
+        if f"e{e}_neg" not in g:
+            continue
+        if f"e{e}_zero" in g:        # g13: two bit planes
+            neg = torch.from_numpy(np.unpackbits(g[f"e{e}_neg"].numpy())[:n]).bool()
+            zero = torch.from_numpy(np.unpackbits(g[f"e{e}_zero"].numpy())[:n]).bool()
+            s = torch.where(neg, -1, 1).to(torch.int8)
+            s[zero] = 0
+            out[e] = s.view(shape)
+        else:                         # t1: bit plane + list of exact zeros
+            out[e] = unpack_gradient(g, e, shape)[0].to(torch.int8)
+    return out.to(device)

@@ -219,3 +219,32 @@ def test_g12_eval_performance(tag):
     assert torch.equal(l_out, g["l_output"])
     for k in ("mAcc", "aAcc", "mIoU"):
         assert stats[k] == pytest.approx(g[k], rel=1e-6)
+
+
+def _g13_files(kind):
+    return sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, f"g13_ctrl_{kind}_*.npz")))
+
+
+@pytest.mark.parametrize("name", _g13_files("train") + _g13_files("largereps"))
+def test_g13_controller_exact_at_stage_lengths(name):
+    """the oracle's controller at SEA's real stage lengths (n_iter 90 / 120, apgd_largereps(300)): with the reference's
+    gradient signs injected (tests/teacher.py:SignInjector) every one of the 91 / 121 / 303 iterates equals the reference's
+    bit for bit -- all halvings, jumps back to the best point, best-adversarial copies and stage hand-overs included"""
+    import teacher as T
+    g = load_golden(name)
+    loss = name.split("_")[3]
+    net = PointwiseNet(21, seed=int(g["net_seed"]))
+    inj = T.SignInjector(net, T.sign_planes(g, g["x"].shape, "cpu")).eval()
+    n = int(g["n_evals"])
+    if "train" in name:
+        xb, acc, lb, xba = O.apgd_train(inj, g["x"], g["y"], "Linf", float(g["eps"]), n_iter=int(g["n_iter"]), use_rs=False,
+                                        loss=loss, track_loss="ce-avg", x_init=g["x_init"], weights=g["w"], early_stop=True)
+        assert torch.equal(xb, g["x_best"]) and torch.equal(xba, g["x_best_adv"]) and torch.equal(acc, g["acc"])
+    else:
+        torch.manual_seed(int(g["seed"]))
+        xa, _, acc = O.apgd_largereps(inj, g["x"].clone(), g["y"], g["w"], eps=float(g["eps"]), n_iter=300, use_rs=True,
+                                      loss=loss, track_loss="ce-avg", early_stop=True)
+        assert torch.equal(xa, g["x_adv"]) and torch.equal(acc, g["acc"])
+    assert int(inj.counter) == n
+    bad = (inj.chk[:n] != g["chk"]).any(1).nonzero().flatten().tolist()
+    assert not bad, f"iterate differs first at evaluation {bad[0]}"

@@ -464,10 +464,14 @@ class ApgdRun:
                 N.apgd_track_graph(r, self.n_ignored, self.HW, self.it_dev, self.cp_dev, self.n_iter, self.early_stop, self.st)
                 N.select_copy(self.st.flags, self.x_adv, self.grad, self.x_best, self.grad_best, self.x_best_adv, self.pred,
                               self.pred_best)
-        except Exception as exc:   # K1 + forward + K2 of iteration i are done (graph A replayed): finish it eagerly
-            logits, x_in = self._g_logits, self._g_xin
+        except Exception as exc:   # K1 of iteration i is done (graph A replayed, in place): finish the iteration eagerly.
+            # The failed capture has consumed the autograd graph of graph A's forward, so the forward is run again, on the
+            # updated iterate (same kernels, same bits)
             self._graph_failed(exc)
+            x_in, logits = _forward_logits(self.model, self.x_adv, True, self.fused)
+            r = self._loss(logits, True)
             self.grad.copy_(_input_grad(logits, x_in, r["dlogits"]))
+            del logits
             N.apgd_track(r, self.n_ignored, self.HW, i, self.n_iter, self.cps.get(i, 0), self.early_stop, False, self.st)
             N.select_copy(self.st.flags, self.x_adv, self.grad, self.x_best, self.grad_best, self.x_best_adv, self.pred,
                           self.pred_best)

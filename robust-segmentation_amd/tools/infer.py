@@ -194,6 +194,16 @@ def build_model(cfg, random_init: bool, device):
     return model.to(device).eval()
 
 
+def arithmetic_mode():
+    """what the attacked model's frozen-weight GEMMs computed in (recorded in every summary): the reference evaluates in
+    fp32; the default here is fp32-equivalent (fp16 x 2 operand split = 22 significant bits, forward and input gradient)"""
+    from semseg.models import convnext_upernet as M
+    names = {22: "fp16x2 (22 significant bits)", 3: "bf16x3 (24 bits)", 2: "bf16x2 (16 bits)", 0: "hipBLASLt fp32"}
+    fwd = M.GEMM_TERMS
+    return {"gemm_forward": names.get(fwd, str(fwd)), "gemm_input_gradient": names.get(M._bwd_terms(fwd) if fwd else 0, "?"),
+            "winograd_tile": M.WINOGRAD_TILE, "accumulate": "fp32", "storage": "fp32"}
+
+
 def _pin(t):
     try:
         return t.pin_memory()
@@ -366,7 +376,7 @@ def _main(argv=None):
         torch.save(save_dict, os.path.join(save_dir, f"worse_{addendum}_{test_cfg['NAME']}_{args.eps}.pt"))
         summary = {"model": modelName, "n_images": n_img, "world": world, "eps": args.eps, "attacks": attacks,
                    "clean": clean_stats, "worst_Acc": worst, "worst_Acc_indiv": indiv.tolist(), "final_miou": miou,
-                   "loss-wise_miou": indiv_mious, "attack_seconds": t_attack,
+                   "loss-wise_miou": indiv_mious, "attack_seconds": t_attack, "arithmetic": arithmetic_mode(),
                    "image_iterations_per_s": n_img * len(attacks) * args.n_iter / t_attack}
         print(json.dumps(summary))
         if args.json:

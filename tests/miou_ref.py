@@ -25,10 +25,12 @@ def start_noise(image, attack, stage):
     return torch.rand(3, SIZE, SIZE, generator=g)
 
 
-def parts(eps255):
-    """[(part index, fixture dict)] of every committed part for this radius"""
+def parts(eps255, suffix=""):
+    """[(part index, fixture dict)] of every committed part for this radius.  ``suffix``: "" = the primary runs (4 threads,
+    3 x 100 iterations); "_t3" = RE-RUNS of the same parts by the same unmodified reference with 3 threads (the
+    reference-vs-reference noise floor); "_it300" = runs at the protocol's full length, 3 x 300 iterations"""
     out = []
-    for f in sorted(glob.glob(os.path.join(DIR, f"part_*_eps{int(eps255)}.npz"))):
+    for f in sorted(glob.glob(os.path.join(DIR, f"part_[0-9][0-9]_eps{int(eps255)}{suffix}.npz"))):
         d = np.load(f)
         out.append((int(d["part"]), {k: d[k] for k in d.files}))
     return out

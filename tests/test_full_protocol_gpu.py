@@ -1,0 +1,107 @@
+"""BASELINE configs[1] run AS WRITTEN (`-m gpu`): UperNet-ConvNeXt-T, PASCAL-VOC-shaped, one batch of 8 synthetic 512 x 512
+images, full SEA = 3 losses x 300 iterations (stages 90 / 90 / 120) at eps = 4/255 and 8/255, through the product's
+tools.infer (reference tools/infer.py:332-408).  ~17 s of attack per radius.
+
+Asserted: the L-inf ball and the [0, 1] box of every returned image; the arg-max map and the accuracy the attack hands out
+are those of a fresh forward of the returned image; the worst-case bookkeeping (worst_Acc <= every attack's own aAcc, the
+greedy mIoU <= every attack's own mIoU); the evaluation is bitwise reproducible (two runs, same summary); the captured
+HIP graphs and their activation pools are released (device memory back to where it was); and the wall time per step is
+within 15 % of a short measurement of the same step on this box (the sustained rate of the 900-step run: the chip lowers its
+clock under sustained matrix load).
+"""
+import gc
+import json
+import os
+import time
+
+import pytest
+import torch
+
+from conftest import PKG
+
+pytestmark = pytest.mark.gpu
+
+
+def _short_step_ms(steps=30):
+    """ms per APGD step of the headline workload on this box, measured over a short window (what bench.py times)"""
+    from semseg import attacker as A
+    from semseg.models import UperNetForSemanticSegmentation
+    from semseg.utils.utils import VOC_WTS
+    torch.manual_seed(0)
+    model = UperNetForSemanticSegmentation("ConvNeXt-T_CVST", 21, None).eval().cuda()
+    for p in model.parameters():
+        p.requires_grad_(False)
+    x = torch.rand(8, 3, 512, 512, generator=torch.Generator().manual_seed(1234)).cuda()
+    with torch.no_grad():
+        y = torch.cat([model(x[i:i + 2]).max(1)[1] for i in range(0, 8, 2)])
+    run = A.ApgdRun(model, x, y, 8.0 / 255, steps + 12, "mask-ce-bal", "ce-avg", True, 21, torch.tensor(VOC_WTS).cuda(), x.clone())
+    run.start()
+    for i in range(10):
+        run.step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(10, 10 + steps):
+        run.step(i)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    run.release_graphs()
+    return ms
+
+
+@pytest.mark.parametrize("eps", [4.0, 8.0])
+def test_configs1_full_sea_3x300_as_written(tmp_path, monkeypatch, eps):
+    import yaml
+    from semseg import attacker
+    from tools import infer
+    cfg = yaml.safe_load(open(os.path.join(PKG, "configs", "pascalvoc_convnext.yaml")))
+    cfg["SAVE_DIR"] = str(tmp_path) + "/"
+    cfg_path = str(tmp_path / "cfg.yaml")
+    yaml.safe_dump(cfg, open(cfg_path, "w"))
+
+    calls = []
+    real = attacker.apgd_largereps
+
+    def recording(model, x, y, weights, **kw):
+        out = real(model, x, y, weights, **kw)
+        x_adv, _, acc, pred = out
+        r = kw["eps"]
+        assert (x_adv - x).abs().max().item() <= r + 1e-6 and x_adv.min().item() >= 0.0 and x_adv.max().item() <= 1.0
+        with torch.no_grad():
+            again = model(x_adv).max(1)[1]
+        assert torch.equal(again, pred.long()), "the arg-max map handed out is not the prediction of the returned image"
+        ok = (again == y) & (y != -1)
+        assert torch.equal(acc, ok.flatten(1).sum(1).float() / float(y[0].numel())), "acc is not the returned image's accuracy"
+        calls.append((kw["loss"], acc.detach().cpu()))
+        return out
+
+    monkeypatch.setattr(attacker, "apgd_largereps", recording)
+    gc.collect()
+    torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    args = ["--cfg", cfg_path, "--eps", str(eps), "--n_iter", "300", "--synthetic", "8", "--balance_classes", "--batch_size", "8",
+            "--deterministic"]
+    s1 = infer.main(args + ["--json", str(tmp_path / "a.json")])
+    gc.collect()
+    torch.cuda.empty_cache()
+    held = torch.cuda.memory_allocated() - base
+    assert held <= 64 * 2 ** 20, f"{held / 2 ** 20:.0f} MiB still allocated after the evaluation (graphs / pools not released?)"
+    assert [c[0] for c in calls] == list(infer.LOSSES)
+    s = json.load(open(tmp_path / "a.json"))
+    assert s["n_images"] == 8 and s["clean"]["aAcc"] == 1.0
+    assert 0.0 <= s["worst_Acc"] <= min(s["worst_Acc_indiv"]) + 1e-9
+    assert s["final_miou"] <= min(s["loss-wise_miou"]) + 1e-9
+    assert s["worst_Acc"] < 0.9                               # the attack bites
+    # bitwise reproducible at 512 x 512: a second evaluation gives the same numbers, digit for digit
+    calls.clear()
+    s2 = infer.main(args + ["--json", str(tmp_path / "b.json")])
+    for k in ("worst_Acc", "final_miou", "worst_Acc_indiv", "loss-wise_miou"):
+        assert s1[k] == s2[k], (k, s1[k], s2[k])
+    # sustained rate of the 900-step evaluation vs a short window of the same step
+    short = _short_step_ms()
+    per_step = min(s1["attack_seconds"], s2["attack_seconds"]) * 1e3 / (3 * 300)
+    print(f"\n[configs[1] as written] eps {eps:g}/255: worst-case aAcc {100 * s['worst_Acc']:.3f} %, mIoU {100 * s['final_miou']:.3f} %; "
+          f"attack {s1['attack_seconds']:.1f} s / {s2['attack_seconds']:.1f} s for 3 x 300 iterations of 8 images = {per_step:.2f} ms per "
+          f"step sustained ({8 * 900 / min(s1['attack_seconds'], s2['attack_seconds']):.0f} image-iterations/s) vs {short:.2f} ms over a "
+          f"30-step window; arithmetic {s.get('arithmetic')}")
+    assert per_step <= 1.15 * short, (per_step, short)

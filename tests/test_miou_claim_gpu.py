@@ -1,25 +1,37 @@
 """The north_star's second metric, against the REFERENCE ITSELF: |mIoU_build - mIoU_reference| and
-|aAcc_build - aAcc_reference| of a full SEA evaluation (3 losses x 100 iterations, worst case over the attacks:
-reference tools/infer.py:332-408, tools/worse_only.py:279-334, 351-422).  `-m gpu`.
+|aAcc_build - aAcc_reference| of a full SEA evaluation (3 losses, worst case over the attacks: reference
+tools/infer.py:332-408, tools/worse_only.py:279-334, 351-422).  `-m gpu`.
 
 Reference side: tests/golden/miou_ref/ holds the per-attack per-image intersection / union tables that the REAL
 reference produced on CPU (oracle/gen_miou_reference.py: unmodified apgd_largereps + evalSEA) on parts of 64 synthetic
 128x128 images; nothing of the reference or of the CPU oracle runs on the GPU box.  Device side: the product path
 (tools/synth.sea_evaluate = the loop of tools/infer.py) on the same model, images, labels, batches and random starts.
 
-The attack is a chaotic iteration: two correct implementations (and the reference against itself with a different
-thread count) end in different adversarial images, so the worst-case statistics agree statistically, not image by
-image.  The test therefore reports, per radius, the PAIRED per-image difference of the worst-case accuracy with its
-95 % confidence interval, and the difference of the worst-case mIoU with a paired bootstrap interval over images, and
-asserts that the difference is (a) within the north_star's 0.05 points or (b) within 1.5 x its own 95 % half-width
-(= 3 standard errors), i.e. not distinguishable from zero at the committed sample size.  The acceptance band is 3
-standard errors, not 2: at 128 x 128 the device run itself is not bitwise reproducible (a MIOpen kernel of the PSP branch
-accumulates with atomics), two device runs on the same 512 images differ by 0.1 points, and a 95 % band would
-make this test fail on 1 run in 20 by construction.  The printed interval is the 95 % one.
-Measured values: profiles/r3_miou_vs_reference.log.
-"""
-import random
+The attack is a chaotic iteration: two correct implementations end in different adversarial images, so worst-case
+statistics agree statistically, not image by image.  HOW chaotic is measured, not asserted: parts `*_t3` are RE-RUNS of
+the same parts by the same unmodified reference with 3 instead of 4 CPU threads (another summation order inside its
+convolutions): the reference-vs-reference noise floor.
 
+What is asserted (fixed in advance; no band is widened after a failure):
+
+  eps = 4/255   the claim itself: |diff| <= 0.05 points for aAcc and mIoU, at a sample size whose 95 % interval half-width
+                is itself <= 0.05 (asserted too).
+  eps = 8/255   the per-image standard deviation is 2.2 points (the attack drives most images towards 0 % along chaotic
+                trajectories), so 0.05 points needs N ~ 7 400 images and is NOT resolved by the committed parts; the test
+                says so in its output and asserts what CAN be falsified at the committed N:
+                (a) the device deviates from the reference NO MORE than the reference deviates from itself: one-sided
+                    Mann-Whitney U of the per-image |diff| device-vs-reference against reference-vs-reference, p > 0.01;
+                (b) the signed per-image differences have the reference-vs-reference distribution: two-sample
+                    Kolmogorov-Smirnov, p > 0.01 (a bias of the size of the claim's band shifts this distribution);
+                (c) the mean difference is inside its 99 % interval around zero (|mean| <= 2.58 standard errors), and so
+                    is its distance to the reference-vs-reference mean (two-sample z).
+                (a) and (b) are skipped (with a message) while no re-run part is committed.
+  3 x 300       where a part at the protocol's full length is committed (`*_it300`): the same assertions as its radius.
+
+The device run is made bitwise reproducible for this test (the 3x3 convolutions on the 4x4 and 8x8 maps of a 128x128 input
+go through the Winograd path instead of a MIOpen kernel that accumulates with atomics), so the test's outcome is a function
+of the committed fixtures and the code, not of chance.  Measured values: profiles/r4_miou_vs_reference.log.
+"""
 import numpy as np
 import pytest
 import torch
@@ -31,20 +43,22 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def model():
-    from semseg.models import UperNetForSemanticSegmentation
+    from semseg.models import UperNetForSemanticSegmentation, convnext_upernet as M
     torch.manual_seed(0)
     m = UperNetForSemanticSegmentation("ConvNeXt-T_CVST", R.C, None).eval().cuda()
     with torch.no_grad():
         m.decode_head.classifier.bias.copy_(R.bias().cuda())
-    return m
+    old, M.WINOGRAD_MIN_PIXELS = M.WINOGRAD_MIN_PIXELS, 16      # every 3x3 ConvModule on the reproducible path
+    yield m
+    M.WINOGRAD_MIN_PIXELS = old
 
 
-def _device_tables(model, eps255):
+def _device_tables(model, eps255, plist):
     from semseg.utils.utils import VOC_WTS
     from tools.synth import sea_evaluate
     w = torch.tensor(VOC_WTS)
     ref_i, ref_u, dev_i, dev_u = [], [], [], []
-    for part, d in R.parts(eps255):
+    for part, d in plist:
         images = R.part_images(part)
         labels = torch.from_numpy(d["labels"]).long()
         with torch.no_grad():                                   # the labels ARE the model's clean prediction
@@ -65,35 +79,102 @@ def _device_tables(model, eps255):
     return cat(ref_i), cat(ref_u), cat(dev_i), cat(dev_u)
 
 
-@pytest.mark.parametrize("eps255", [8, 4])
-def test_worst_case_metrics_match_the_reference(model, eps255):
-    if not R.parts(eps255):
-        pytest.skip(f"no reference part committed for eps {eps255}/255")
-    ref_i, ref_u, dev_i, dev_u = _device_tables(model, eps255)
+def _paired(ref_i, ref_u, oth_i, oth_u, seed=225):
+    """paired statistics of `other` against the reference on the same images: (aAcc ref, other, mean diff, sd, n), (mIoU ref,
+    other, diff, bootstrap 95 % interval), per-image signed differences of the worst-case accuracy (points)"""
     n = ref_i.shape[1]
     valid = torch.full((n,), R.SIZE * R.SIZE)
     acc_r, miou_r, per_r = R.worst_case(ref_i, ref_u, valid)
-    acc_d, miou_d, per_d = R.worst_case(dev_i, dev_u, valid)
-    # ---- aAcc: paired per-image differences of the worst-case accuracy (points)
-    diff = (per_d - per_r).double()
-    d_acc, sd = diff.mean().item(), diff.std(unbiased=True).item()
-    ci_acc = 1.96 * sd / n ** 0.5
-    # ---- mIoU: dataset-level statistic -> paired bootstrap over images (same resample for both sides)
-    rng = np.random.default_rng(225)
+    acc_o, miou_o, per_o = R.worst_case(oth_i, oth_u, valid)
+    diff = (per_o - per_r).double()
+    rng = np.random.default_rng(seed)
     boots = []
     for _ in range(200):
         idx = torch.from_numpy(rng.integers(0, n, n))
         _, mr, _ = R.worst_case(ref_i[:, idx], ref_u[:, idx], valid)
-        _, md, _ = R.worst_case(dev_i[:, idx], dev_u[:, idx], valid)
-        boots.append(md - mr)
-    d_miou = miou_d - miou_r
+        _, mo, _ = R.worst_case(oth_i[:, idx], oth_u[:, idx], valid)
+        boots.append(mo - mr)
     lo, hi = np.percentile(boots, [2.5, 97.5])
-    ci_miou = max(hi - d_miou, d_miou - lo, 0.0)
-    print(f"\n[SEA vs the real reference] eps {eps255}/255, {n} images of {R.SIZE}^2, 3 x 100 iterations\n"
-          f"  worst-case aAcc  reference {acc_r:8.4f} %   device {acc_d:8.4f} %   paired mean diff {d_acc:+.4f} points, "
-          f"per-image sd {sd:.3f}, 95 % CI half-width {ci_acc:.4f}\n"
-          f"  worst-case mIoU  reference {miou_r:8.4f} %   device {miou_d:8.4f} %   diff {d_miou:+.4f} points, "
-          f"paired bootstrap 95 % interval [{lo:+.4f}, {hi:+.4f}]")
+    return (acc_r, acc_o, diff.mean().item(), diff.std(unbiased=True).item(), n), (miou_r, miou_o, miou_o - miou_r, lo, hi), diff
+
+
+def _reference_floor(eps255, suffix):
+    """per-image signed differences (points) reference re-run minus reference, over every part that has a re-run"""
+    primary = dict(R.parts(eps255, suffix))
+    rer = [(p, d) for p, d in R.parts(eps255, suffix + "_t3") if p in primary]
+    if not rer:
+        return None
+    cat = lambda key, src: torch.cat([torch.from_numpy(src(p, d)[key]).long() for p, d in rer], 1)
+    a = _paired(cat("ints", lambda p, d: primary[p]), cat("unions", lambda p, d: primary[p]),
+                cat("ints", lambda p, d: d), cat("unions", lambda p, d: d), seed=226)
+    return a
+
+
+def _run(model, eps255, suffix, tag):
+    from scipy import stats
+    plist = R.parts(eps255, suffix)
+    if not plist:
+        pytest.skip(f"no reference part committed for eps {eps255}/255{' at 3 x 300' if suffix else ''}")
+    ref_i, ref_u, dev_i, dev_u = _device_tables(model, eps255, plist)
+    (acc_r, acc_d, d_acc, sd, n), (miou_r, miou_d, d_miou, lo, hi), diff = _paired(ref_i, ref_u, dev_i, dev_u)
+    se = sd / n ** 0.5
+    ci_acc, ci_miou = 1.96 * se, max(hi - d_miou, d_miou - lo, 0.0)
+    n_iter = int(plist[0][1]["n_iter"])
+    lines = [f"[SEA vs the real reference{tag}] eps {eps255}/255, {n} images of {R.SIZE}^2, 3 x {n_iter} iterations",
+             f"  worst-case aAcc  reference {acc_r:8.4f} %   device {acc_d:8.4f} %   paired mean diff {d_acc:+.4f} points, "
+             f"per-image sd {sd:.3f}, 95 % CI half-width {ci_acc:.4f}",
+             f"  worst-case mIoU  reference {miou_r:8.4f} %   device {miou_d:8.4f} %   diff {d_miou:+.4f} points, "
+             f"paired bootstrap 95 % interval [{lo:+.4f}, {hi:+.4f}]"]
+    floor = _reference_floor(eps255, suffix)
+    checks = []
+    if floor is not None:
+        (facc_r, facc_o, f_acc, fsd, fn), (fm_r, fm_o, f_miou, flo, fhi), fdiff = floor
+        lines += [f"  reference vs ITSELF (3 threads vs 4, {fn} images): worst-case aAcc {facc_r:.4f} / {facc_o:.4f} %, paired mean "
+                  f"diff {f_acc:+.4f} points, per-image sd {fsd:.3f}, 95 % CI half-width {1.96 * fsd / fn ** 0.5:.4f};  "
+                  f"mIoU diff {f_miou:+.4f} [{flo:+.4f}, {fhi:+.4f}]",
+                  f"  per-image |diff|: device-vs-reference median {diff.abs().median():.4f} mean {diff.abs().mean():.4f};  "
+                  f"reference-vs-reference median {fdiff.abs().median():.4f} mean {fdiff.abs().mean():.4f}"]
+        if fdiff.abs().max() == 0:
+            lines.append("  (the re-run reproduced the reference bit for bit: no noise floor to compare with)")
+        else:
+            p_mw = stats.mannwhitneyu(diff.abs().numpy(), fdiff.abs().numpy(), alternative="greater").pvalue
+            p_ks = stats.ks_2samp(diff.numpy(), fdiff.numpy()).pvalue
+            z2 = abs(d_acc - f_acc) / (se ** 2 + fsd ** 2 / fn) ** 0.5
+            lines.append(f"  device deviates more than the reference from itself?  Mann-Whitney (one-sided) p = {p_mw:.3f};  "
+                         f"signed differences, two-sample KS p = {p_ks:.3f};  mean vs floor mean z = {z2:.2f}")
+            checks += [("Mann-Whitney p > 0.01", p_mw > 0.01), ("KS p > 0.01", p_ks > 0.01), ("two-sample z <= 2.58", z2 <= 2.58)]
+    else:
+        lines.append("  (no reference re-run committed for this radius / length: distribution tests skipped)")
+    resolved = ci_acc <= 0.05 and ci_miou <= 0.05
+    if resolved:
+        checks += [("|aAcc diff| <= 0.05", abs(d_acc) <= 0.05), ("|mIoU diff| <= 0.05", abs(d_miou) <= 0.05)]
+        lines.append("  the 0.05-point claim is RESOLVED at this sample size (both 95 % half-widths <= 0.05)")
+    else:
+        need = int((1.96 * sd / 0.05) ** 2)
+        lines.append(f"  the 0.05-point claim is NOT resolved at this sample size (half-widths {ci_acc:.3f} / {ci_miou:.3f}; "
+                     f"needs N ~ {need} images): asserting the 99 % interval around zero instead")
+        checks += [("|aAcc diff| <= 2.58 SE", abs(d_acc) <= 2.58 * se),
+                   ("|mIoU diff| <= 1.32 x bootstrap 95 % half-width (= 99 %)", abs(d_miou) <= 1.32 * ci_miou)]
+    lines.append("  " + ";  ".join(f"{name}: {'ok' if ok else 'FAILED'}" for name, ok in checks))
+    print("\n" + "\n".join(lines))
     assert 1.0 < miou_r < 60.0 and 1.0 < acc_r < 90.0           # the attack bites and the metrics are not degenerate
-    assert abs(d_acc) <= max(0.05, 1.5 * ci_acc), (d_acc, ci_acc)
-    assert abs(d_miou) <= max(0.05, 1.5 * ci_miou), (d_miou, ci_miou)
+    return resolved, checks
+
+
+def test_eps4_claim_within_0p05_points_of_the_reference(model):
+    """eps = 4/255: resolved at the committed N: |aAcc diff| and |mIoU diff| <= 0.05 points, both 95 % half-widths <= 0.05"""
+    resolved, checks = _run(model, 4, "", "")
+    assert resolved, "the committed eps-4 parts no longer resolve 0.05 points"
+    assert all(ok for _, ok in checks), checks
+
+
+def test_eps8_device_is_indistinguishable_from_the_reference_rerun(model):
+    resolved, checks = _run(model, 8, "", "")
+    assert all(ok for _, ok in checks), checks
+
+
+@pytest.mark.parametrize("eps255", [4, 8])
+def test_full_length_3x300_parts(model, eps255):
+    """parts generated at the protocol's real length (3 x 300 iterations, stages 90 / 90 / 120)"""
+    resolved, checks = _run(model, eps255, "_it300", " (full length)")
+    assert all(ok for _, ok in checks), checks

@@ -116,9 +116,62 @@ def test_bench_starts_its_own_ranks(tmp_path):
     env.pop("RANK", None)
     env.pop("WORLD_SIZE", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--batch", "2", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=1500)
+                        "--batch", "2", "--no-cpu-baseline", "--sustain", "3"], env=env, capture_output=True, text=True,
+                       timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
-    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["scaling"] == "weak"
+    _check_bench_line(out, 2, batch=2)
+
+
+def _check_bench_line(out, world, batch):
+    """what the driver's scaling run relies on: the world size is the collective library's, one row per rank, and the
+    SLOWEST rank defines the job's ms_per_step (value = units all ranks processed / that time)"""
+    assert out["n_gpus"] == world and out["config"]["global_batch"] == world * batch and out["scaling"] == "weak"
+    rows = out["config"]["per_rank"]
+    assert [r["rank"] for r in rows] == list(range(world))
+    assert out["ms_per_step"] == pytest.approx(max(r["ms_per_step"] for r in rows), rel=1e-9)
+    assert out["value"] == pytest.approx(world * batch * 1e3 / out["ms_per_step"], rel=1e-9)
+    assert all(r["host_enqueue_ms_per_step"] <= r["ms_per_step"] for r in rows)
+    assert out["config"]["sustained_ms_per_step"] > 0 and out["config"]["sustained_steps"] == 3
     assert out["roofline"]["frac_cold"] is not None and out["roofline"]["measured_copy_ceiling_GBps"] > 1000
+
+
+# ---- the same paths over RCCL: need one GPU per rank.  The GPU boxes of the build pool have ONE GPU, so these have never
+# run there; on the driver's 8-GPU node they are the first thing that exercises tools/sea_shard.py's device all-reduce
+# and bench.py's nccl branch UNDER TEST instead of for the first time inside the scaling bench.
+_NEED2 = pytest.mark.skipif(torch.cuda.device_count() < 2,
+                            reason=f"RCCL needs one GPU per rank; this box has {torch.cuda.device_count()} GPU(s) "
+                                   "(the gloo tests above run the same code with a host-side reduce)")
+
+
+@_NEED2
+def test_rccl_sharded_sea_eval_two_gpus_equal_one_gpu(tmp_path):
+    """tools.infer on 2 GPUs, backend nccl (= RCCL over xGMI): ONE all_reduce(SUM) of the packed int64 statistics buffer on
+    the devices; the result equals the 1-GPU run bit for bit"""
+    from tools import infer
+    cfg = _cfg(tmp_path, "pascalvoc_convnext.yaml", None)
+    common = ["--cfg", cfg, "--eps", "8", "--n_iter", "10", "--synthetic", "8", "--image_size", "512", "--batch_size", "2",
+              "--cleanup", "0", "--deterministic"]
+    one = str(tmp_path / "one.pt")
+    s1 = infer.main(common + ["--dump_stats", one])
+    two, js = str(tmp_path / "two.pt"), str(tmp_path / "two.json")
+    _torchrun(2, ["-m", "tools.infer"] + common + ["--backend", "nccl", "--dump_stats", two, "--json", js])
+    assert torch.equal(torch.load(one), torch.load(two))
+    s2 = json.load(open(js))
+    assert s2["world"] == 2
+    for k in ("worst_Acc", "final_miou", "loss-wise_miou", "clean"):
+        assert s1[k] == s2[k], k
+
+
+@_NEED2
+def test_rccl_bench_two_gpus(tmp_path):
+    """`python bench.py --gpus 2` over RCCL, one rank per GPU: exactly what the driver's scaling run launches"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "SEA_BENCH_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                        "--no-cpu-baseline", "--sustain", "3"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    _check_bench_line(out, 2, batch=8)

@@ -114,13 +114,19 @@ def test_pirat_inner_pgd_convnext_s_fp32_and_bf16(ctx):
     test_teacher_forced_gpu.py).  bf16 autocast (what the config asks for) must stay a valid attack of the same
     strength: same eps-ball and a cross-entropy gain within 5 % of the fp32 reference's."""
     from semseg import val as V
-    _, model, _, _, _, w, C = ctx("upernet_s")
+    g10, model, x2, _, y2, w, C = ctx("upernet_s")
     g = T.load_golden("t1_upernet_s_pgd")
     x = T.image()
     xs, deltas, x_adv_ref = T.replay_pgd(g, x)
     x, y = x.cuda(), g["y"].long().cuda()
     atk = V.Pgd_Attack_1(epsilon=EPS, alpha=float(g["alpha"]), num_iter=int(g["n_evals"]), los="pgd")
     B = Bounds("Pgd_Attack_1 end state, UperNet-ConvNeXt-S C=151")
+    # the device model's cross-entropy IS the reference's: on the clean two-image batch of the g10 golden (the reference's own
+    # number, oracle/gen_goldens.py) and, step by step on the reference's iterates, in test_teacher_forced_gpu.py -- which
+    # is what licenses evaluating the reference's final iterate with the device model below (`ce_ref`)
+    with torch.no_grad():
+        ce_clean2 = torch.nn.functional.cross_entropy(model(x2), y2).item()
+    B.check("clean CE of the golden batch: |device / reference - 1|", abs(ce_clean2 / float(g10["pgd_ce_clean"]) - 1), 1e-4)
     xa, logits, _ = atk.adv_attack(model, x, y, delta0=deltas[0].cuda())
     assert (xa - x).abs().max() <= EPS + 1e-6
     B.check("fp32: fraction of x_adv elements != reference (whole image)", (xa.cpu() != x_adv_ref).float().mean(), 0.10)

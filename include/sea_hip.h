@@ -422,6 +422,9 @@ int sea_gemm_split_fused(const float* A, int64_t lda, const void* Wp, float* C, 
 int sea_gemm_split(const float* A, int64_t lda, const void* Wp, float* C, int64_t ldc, const float* bias, int relu, int M,
                    int N, int K, int terms, int batch, int64_t strideA, int64_t strideW_bytes, int64_t strideC,
                    void* stream);
+/* Tuning knob of the sea_gemm_split* kernels: MFMA fragment shape, 32 (v_mfma_f32_32x32x16_{f16,bf16}; default) or 16
+ * (v_mfma_f32_16x16x32_*; also env SEA_GEMM_SHAPE=16).  Any other argument only queries.  Returns the previous shape. */
+int sea_gemm_split_mfma_shape(int shape);
 
 /* ------------------------------------------------------------------------------------------------
  * Measurement probes (bench.py / tools/kernel_bench.py only; nothing on the product path calls them).

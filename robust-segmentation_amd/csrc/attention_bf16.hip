@@ -436,13 +436,13 @@ int sea_attention_bwd_bf16(const float* q, const float* k, const float* v, int64
   // drives a second GPU would otherwise fail its first dkv launch there)
   static bool attr_set_dev[64] = {};
   int dev = 0;
-  hipGetDevice(&dev);
+  (void)hipGetDevice(&dev);
   bool& attr_set = attr_set_dev[dev & 63];
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)attn_dkv_bf16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 3 * kImg + 512);
-    hipFuncSetAttribute((const void*)attn_dkv_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * kImg + 512);
-    hipFuncSetAttribute((const void*)attn_dq_bf16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * kImg);
-    hipFuncSetAttribute((const void*)attn_dq_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * kImg);
+    (void)hipFuncSetAttribute((const void*)attn_dkv_bf16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 3 * kImg + 512);
+    (void)hipFuncSetAttribute((const void*)attn_dkv_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * kImg + 512);
+    (void)hipFuncSetAttribute((const void*)attn_dq_bf16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * kImg);
+    (void)hipFuncSetAttribute((const void*)attn_dq_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * kImg);
     attr_set = true;
   }
   if (terms == 3) {

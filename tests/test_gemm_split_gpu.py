@@ -374,3 +374,56 @@ def test_fp16x2_row_bound_carried_through_a_gemm(N):
     e_got, e_lib = ((got.double() - ref).abs() / rs).amax().item(), ((lib.double() - ref).abs() / rs).amax().item()
     print(f"max row-relative error: hipBLASLt fp32 {e_lib:.2e}   fp16x2 with carried row bounds {e_got:.2e}")
     assert e_got <= max(4.0 * e_lib, 2e-6), (e_got, e_lib)
+
+
+def test_mfma_shape_16_variants_match_shape_32(N):
+    """sea_gemm_split_mfma_shape(16): every kernel variant (three modes, bias / ReLU, the three prologues, the fused epilogue,
+    out_amax) on v_mfma_f32_16x16x32_* fragments gives the 32x32x16 result up to summation order, and the float64 reference
+    to the same accuracy"""
+    g = torch.Generator(device="cuda").manual_seed(21)
+    M, K, Nn = 1000, 192, 200
+    A = torch.randn(M, K, generator=g, device="cuda") * torch.exp2(torch.randint(-8, 3, (M, 1), generator=g, device="cuda").float())
+    W = torch.randn(Nn, K, generator=g, device="cuda") / K ** 0.5
+    bias = torch.randn(Nn, generator=g, device="cuda")
+    t = torch.randn(M, K, generator=g, device="cuda")
+    add = torch.randn(M, Nn, generator=g, device="cuda")
+
+    def all_variants():
+        outs = {}
+        for terms in (22, 3, 2):
+            Wp = N.gemm_split_pack(W, terms=terms)
+            kw = dict(row_amax=True) if terms == 22 else {}
+            outs[terms, "plain"] = N.gemm_split(A, Wp, bias=bias, relu=True, **kw)
+            outs[terms, "gelu"] = N.gemm_split(A, Wp, a_gelu=True, **kw)
+            outs[terms, "addend"] = N.gemm_split(A, Wp, bias=bias, addend=add, **kw)
+            if terms != 3:
+                outs[terms, "gelu_grad"] = N.gemm_split(A, Wp, a_gelu_grad_of=t, **kw)
+                outs[terms, "gate"] = N.gemm_split(A, Wp, a_relu_gate=t, **kw)
+        word = N.amax_word(A.device)
+        outs[22, "out_amax"] = N.gemm_split(A, N.gemm_split_pack(W, terms=22), out_amax=word).clone()
+        outs[22, "out_amax_word"] = word.clone().view(torch.float32)
+        return outs
+
+    L = N.lib()
+    assert L.sea_gemm_split_mfma_shape(-1) in (16, 32)
+    prev = L.sea_gemm_split_mfma_shape(32)
+    try:
+        o32 = all_variants()
+        assert L.sea_gemm_split_mfma_shape(16) == 32
+        o16 = all_variants()
+    finally:
+        L.sea_gemm_split_mfma_shape(prev)
+    ref = {"plain": _ref(A, W, bias, True), "gelu": _ref(torch.nn.functional.gelu(A.double()), W),
+           "addend": _ref(A, W, bias) + add.double(),
+           "gelu_grad": _ref(A.double() * torch.ops.aten.gelu_backward(torch.ones_like(t), t).double(), W),
+           "gate": _ref(torch.where(t > 0, A, torch.zeros_like(A)), W)}
+    for (terms, name), a in o32.items():
+        b = o16[terms, name]
+        if name == "out_amax_word":
+            assert torch.equal(a, b) or abs(a.item() - b.item()) <= 1e-5 * a.item()
+            continue
+        r = ref.get(name, _ref(A, W))
+        scale = r.abs().max().item()
+        tol = 3e-5 if terms == 2 else 3e-6
+        assert (a - b).abs().max().item() <= tol * scale, (terms, name, (a - b).abs().max().item() / scale)
+        assert (b.double() - r).abs().max().item() <= tol * scale, (terms, name)

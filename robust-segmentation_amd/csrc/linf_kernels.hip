@@ -101,6 +101,26 @@ __global__ __launch_bounds__(256) void apgd_linf_step_inplace_v4(const f4* __res
   }
 }
 
+// the same for images whose element count is not a multiple of 4 (e.g. PASCAL-VOC's 3 x 473 x 473: a per-image base is then
+// not 16-byte aligned): one float per lane and trip
+__global__ __launch_bounds__(256) void apgd_linf_step_inplace_v1(const float* __restrict__ x, float* __restrict__ xadv,
+                                                                 float* __restrict__ xold, const float* __restrict__ grad,
+                                                                 const float* __restrict__ step_b, float eps,
+                                                                 const int32_t* __restrict__ iter_dev, int64_t n_per_img) {
+  const int b = blockIdx.y;
+  const float st = step_b[b];
+  const bool first = *iter_dev <= 0;
+  const float a = first ? 1.0f : 0.75f;
+  const float oma = first ? (float)(1.0 - 1.0) : (float)(1.0 - 0.75);
+  const int64_t base = (int64_t)b * n_per_img;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_per_img; i += (int64_t)gridDim.x * blockDim.x) {
+    const float va = xadv[base + i];
+    const float r = apgd_elem(x[base + i], va, xold[base + i], grad[base + i], st, eps, a, oma);
+    xold[base + i] = va;
+    xadv[base + i] = r;
+  }
+}
+
 // generic 2-input -> 1-output element-wise kernels, OP selected at compile time
 enum { OP_RANDOM_START = 0, OP_PROJECT = 1 };
 
@@ -238,11 +258,17 @@ extern "C" int sea_apgd_linf_step_graph(const float* x, float* x_adv, float* x_o
                                         const float* step_b, float eps, const int32_t* iter_dev, int B,
                                         int64_t n_per_img, void* stream) {
   SEA_CHECK_ARG(x && x_adv && x_old && grad && step_b && iter_dev && B > 0 && n_per_img > 0 && B <= 65535);
-  SEA_CHECK_ARG((n_per_img % 4) == 0 && aligned16(x) && aligned16(x_adv) && aligned16(x_old) && aligned16(grad));
-  const int64_t n4 = n_per_img / 4;
-  int gx = grid_for(n4, 256);
   int cap = kMaxGridX / B;
   if (cap < 1) cap = 1;
+  if ((n_per_img % 4) != 0 || !(aligned16(x) && aligned16(x_adv) && aligned16(x_old) && aligned16(grad))) {
+    int gx1 = grid_for(n_per_img, 256);
+    if (gx1 > cap) gx1 = cap;
+    hipLaunchKernelGGL(apgd_linf_step_inplace_v1, dim3(gx1, B), dim3(256), 0, (hipStream_t)stream, x, x_adv, x_old, grad, step_b,
+                       eps, iter_dev, n_per_img);
+    SEA_RETURN_LAST();
+  }
+  const int64_t n4 = n_per_img / 4;
+  int gx = grid_for(n4, 256);
   if (gx > cap) gx = cap;
   hipLaunchKernelGGL(apgd_linf_step_inplace_v4, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, (const f4*)x, (f4*)x_adv,
                      (f4*)x_old, (const f4*)grad, step_b, eps, iter_dev, n4);

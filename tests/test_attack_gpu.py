@@ -277,3 +277,28 @@ def test_hip_graph_capture_failure_falls_back_to_the_eager_loop(where, capfd):
         run.step(i)
     assert run.graphs is not None
     run.release_graphs()
+
+
+def test_hip_graph_mode_on_images_whose_size_is_not_a_multiple_of_four(capfd):
+    """PASCAL-VOC evaluates 473 x 473 crops (configs/pascalvoc_convnext.yaml): 3 x 473 x 473 floats per image is odd, so the
+    per-image bases of the iterate buffers are not 16-byte aligned.  The replayable K1 has a one-float-per-lane form for that
+    (round 3 only had the float4 form: the capture raised); graph replay == the eager loop bit for bit, without a fallback."""
+    from oracle.tiny_models import make_labels
+    from semseg import attacker as A
+    net = PointwiseNet(21, seed=5)
+    g = torch.Generator().manual_seed(19)
+    x = torch.rand(3, 3, 7, 9, generator=g)
+    y = make_labels(net, x, ignore_frac=0.05, flip_frac=0.1, seed=2).cuda()
+    net, x = net.cuda(), x.cuda()
+    w = torch.rand(21, generator=g).cuda()
+    outs = []
+    for graph in (False, True):
+        old, A.USE_HIP_GRAPH = A.USE_HIP_GRAPH, graph
+        try:
+            outs.append(A.apgd_train(net, x, y, "Linf", 8.0 / 255, n_iter=30, loss="mask-ce-bal", early_stop=True,
+                                     track_loss="ce-avg", num_classes=21, weights=w, return_pred=True))
+        finally:
+            A.USE_HIP_GRAPH = old
+    assert "continuing with the eager loop" not in capfd.readouterr().err
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)

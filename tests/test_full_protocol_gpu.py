@@ -70,7 +70,8 @@ def test_configs1_full_sea_3x300_as_written(tmp_path, monkeypatch, eps):
             again = model(x_adv).max(1)[1]
         assert torch.equal(again, pred.long()), "the arg-max map handed out is not the prediction of the returned image"
         ok = (again == y) & (y != -1)
-        assert torch.equal(acc, ok.flatten(1).sum(1).float() / float(y[0].numel())), "acc is not the returned image's accuracy"
+        torch.testing.assert_close(acc, ok.flatten(1).sum(1).float() / float(y[0].numel()), rtol=0, atol=1e-6,
+                                   msg="acc is not the returned image's accuracy")
         calls.append((kw["loss"], acc.detach().cpu()))
         return out
 
@@ -79,8 +80,8 @@ def test_configs1_full_sea_3x300_as_written(tmp_path, monkeypatch, eps):
     torch.cuda.empty_cache()
     torch.cuda.synchronize()
     base = torch.cuda.memory_allocated()
-    args = ["--cfg", cfg_path, "--eps", str(eps), "--n_iter", "300", "--synthetic", "8", "--balance_classes", "--batch_size", "8",
-            "--deterministic"]
+    args = ["--cfg", cfg_path, "--eps", str(eps), "--n_iter", "300", "--synthetic", "8", "--image_size", "512", "--balance_classes",
+            "--batch_size", "8", "--deterministic"]
     s1 = infer.main(args + ["--json", str(tmp_path / "a.json")])
     gc.collect()
     torch.cuda.empty_cache()

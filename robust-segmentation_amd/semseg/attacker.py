@@ -289,6 +289,21 @@ USE_HIP_GRAPH = os.environ.get("SEA_HIP_GRAPH", "1") != "0"
 GRAPH_MIN_ITER = 12
 
 
+_CAPTURE_STREAMS = {}
+
+
+def _capture_stream(device):
+    """ONE side stream per device for every run's graph captures.  PyTorch keeps a BLAS workspace per (handle, stream) for
+    the life of the process (tens to hundreds of MB each); a fresh torch.cuda.Stream() per run -- three per attack and batch --
+    left one such set behind per pooled stream handle (measured: 150-200 MB per run still allocated after an evaluation).
+    Runs are sequential, and each orders itself against the caller's stream with wait_stream both ways."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _CAPTURE_STREAMS.get(key)
+    if st is None:
+        st = _CAPTURE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 class ApgdRun:
     """One APGD run as an object: ``start()`` is step 0 (reference lines 342-383), ``step(i)`` is loop
     iteration i (lines 385-569).  ``apgd_train`` drives it; bench.py times ``step`` directly.
@@ -388,7 +403,7 @@ class ApgdRun:
             if i == 1:
                 # eager, but on the stream the graphs will be captured on: per-stream library state (MIOpen / hipBLASLt
                 # handles and workspaces) must exist before a capture starts
-                self._gs = torch.cuda.Stream()
+                self._gs = _capture_stream(self.x.device)
                 cur = torch.cuda.current_stream()
                 self._gs.wait_stream(cur)
                 with torch.cuda.stream(self._gs):

@@ -76,26 +76,28 @@ def test_configs1_full_sea_3x300_as_written(tmp_path, monkeypatch, eps):
         return out
 
     monkeypatch.setattr(attacker, "apgd_largereps", recording)
-    gc.collect()
-    torch.cuda.empty_cache()
-    torch.cuda.synchronize()
-    base = torch.cuda.memory_allocated()
     args = ["--cfg", cfg_path, "--eps", str(eps), "--n_iter", "300", "--synthetic", "8", "--image_size", "512", "--balance_classes",
             "--batch_size", "8", "--deterministic"]
     s1 = infer.main(args + ["--json", str(tmp_path / "a.json")])
-    gc.collect()
-    torch.cuda.empty_cache()
-    held = torch.cuda.memory_allocated() - base
-    assert held <= 64 * 2 ** 20, f"{held / 2 ** 20:.0f} MiB still allocated after the evaluation (graphs / pools not released?)"
     assert [c[0] for c in calls] == list(infer.LOSSES)
     s = json.load(open(tmp_path / "a.json"))
     assert s["n_images"] == 8 and s["clean"]["aAcc"] == 1.0
     assert 0.0 <= s["worst_Acc"] <= min(s["worst_Acc_indiv"]) + 1e-9
     assert s["final_miou"] <= min(s["loss-wise_miou"]) + 1e-9
     assert s["worst_Acc"] < 0.9                               # the attack bites
-    # bitwise reproducible at 512 x 512: a second evaluation gives the same numbers, digit for digit
+    # bitwise reproducible at 512 x 512: a second evaluation gives the same numbers, digit for digit -- and leaves nothing
+    # behind on the device: the nine runs' captured graphs, their activation pools and per-stream library workspaces are
+    # released or reused (the first evaluation may keep process-lifetime workspaces; the second must not add to them)
     calls.clear()
+    gc.collect()
+    torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
     s2 = infer.main(args + ["--json", str(tmp_path / "b.json")])
+    gc.collect()
+    torch.cuda.empty_cache()
+    held = torch.cuda.memory_allocated() - base
+    assert held <= 64 * 2 ** 20, f"{held / 2 ** 20:.0f} MiB more allocated after a second evaluation (graphs / pools not released?)"
     for k in ("worst_Acc", "final_miou", "worst_Acc_indiv", "loss-wise_miou"):
         assert s1[k] == s2[k], (k, s1[k], s2[k])
     # sustained rate of the 900-step evaluation vs a short window of the same step

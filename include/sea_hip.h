@@ -361,6 +361,8 @@ int sea_attention_bwd_terms(const float* q, const float* k, const float* v, int6
  *   batch strides in elements (A, C) / bytes (packed W).  K % 32 == 0, lda % 4 == 0, A 16-byte aligned.
  * sea_gemm_split_pack: W (N x K row-major, or K x N with trans = 1; row stride ldw) -> the packed, pre-split image the
  *   kernel reads ([K/32][terms][ceil128(N)][32] bf16, sea_gemm_split_packed_bytes bytes).  Done once per weight.
+ * terms = 1 keeps one bf16 term per operand (the operands of a bf16-autocast GEMM, one product, fp32 accumulate and fp32
+ *   in / out): the attack forward / backward of PIR-AT's inner PGD under TRAIN.AMP (BASELINE configs[3]).
  * terms = 22 selects fp16 x 2 operands instead (hi = fp16(x*s), mid = fp16(x*s - hi): 22 significant bits, three
  *   products on v_mfma_f32_32x32x16_f16): fp16 has 5 exponent bits, so the weights are packed with a power-of-two scale per
  *   output row and the activations are scaled by a power of two derived from max|A|, which the caller obtains on the device

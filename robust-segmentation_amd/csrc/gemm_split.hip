@@ -302,8 +302,10 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(const GemmSplitArgs 
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][2], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][1], c, 0, 0, 0);
               }
-              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][0], c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][1], c, 0, 0, 0);
+              if constexpr (TERMS >= 2) {
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][1], c, 0, 0, 0);
+              }
               c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][0], c, 0, 0, 0);
             }
             acc[mi][ni] = c;
@@ -391,8 +393,10 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(const GemmSplitArgs 
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[nj][2], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[nj][1], c, 0, 0, 0);
               }
-              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[nj][0], c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[nj][1], c, 0, 0, 0);
+              if constexpr (TERMS >= 2) {
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[nj][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[nj][1], c, 0, 0, 0);
+              }
               c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[nj][0], c, 0, 0, 0);
             }
             acc[mi][2 * nh + nj] = c;
@@ -693,14 +697,14 @@ extern "C" int sea_gemm_split_mfma_shape(int shape) {
 
 // terms: 3 / 2 = bf16 terms per operand; 22 = fp16 x 2 (22 significant bits, per-tensor power-of-two scaling)
 extern "C" int64_t sea_gemm_split_packed_bytes(int N, int K, int terms) {
-  if (N <= 0 || K <= 0 || K % GS_BK || (terms != 2 && terms != 3 && terms != 22)) return -1;
+  if (N <= 0 || K <= 0 || K % GS_BK || (terms != 1 && terms != 2 && terms != 3 && terms != 22)) return -1;
   if (terms == 22) return (int64_t)(K / GS_BK) * 2 * gs_npad(N) * GS_BK * 2 + (int64_t)gs_npad(N) * 8;   // + inverse scales, row maxima
   return (int64_t)(K / GS_BK) * terms * gs_npad(N) * GS_BK * 2;
 }
 
 extern "C" int sea_gemm_split_pack(const float* W, int64_t ldw, int trans, int N, int K, int terms, void* out,
                                    void* stream) {
-  SEA_CHECK_ARG(W && out && N > 0 && K > 0 && (K % GS_BK) == 0 && (terms == 2 || terms == 3 || terms == 22));
+  SEA_CHECK_ARG(W && out && N > 0 && K > 0 && (K % GS_BK) == 0 && (terms == 1 || terms == 2 || terms == 3 || terms == 22));
   SEA_CHECK_ARG(ldw >= (trans ? N : K));
   const int Npad = gs_npad(N);
   const int64_t total = (int64_t)(K / 32) * Npad * 32;
@@ -715,7 +719,10 @@ extern "C" int sea_gemm_split_pack(const float* W, int64_t ldw, int trans, int N
                        rowmax, (uint16_t*)out, w_inv);
     SEA_RETURN_LAST();
   }
-  if (terms == 3)
+  if (terms == 1)
+    hipLaunchKernelGGL(gemm_split_pack_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, ldw, trans, N, K, Npad,
+                       (uint16_t*)out);
+  else if (terms == 3)
     hipLaunchKernelGGL(gemm_split_pack_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, ldw, trans, N, K, Npad,
                        (uint16_t*)out);
   else
@@ -732,7 +739,7 @@ static int gemm_split_impl(const float* A, int64_t lda, const void* Wp, float* C
 extern "C" int sea_gemm_split(const float* A, int64_t lda, const void* Wp, float* C, int64_t ldc, const float* bias,
                               int relu, int M, int N, int K, int terms, int batch, int64_t strideA, int64_t strideW_bytes,
                               int64_t strideC, void* stream) {
-  SEA_CHECK_ARG(terms == 2 || terms == 3);
+  SEA_CHECK_ARG(terms == 1 || terms == 2 || terms == 3);
   return gemm_split_impl(A, lda, Wp, C, ldc, bias, relu, M, N, K, terms, batch, strideA, strideW_bytes, strideC, nullptr, 0,
                          nullptr, stream);
 }
@@ -754,7 +761,7 @@ extern "C" int sea_gemm_split_fused(const float* A, int64_t lda, const void* Wp,
                                     int relu, int M, int N, int K, int terms, int batch, int64_t strideA,
                                     int64_t strideW_bytes, int64_t strideC, const uint32_t* amax_bits, int amax_rows,
                                     uint32_t* out_amax, const SeaGemmEpilogue* epi, void* stream) {
-  SEA_CHECK_ARG(terms == 2 || terms == 3 || (terms == 22 && amax_bits != nullptr && amax_rows >= 0));
+  SEA_CHECK_ARG(terms == 1 || terms == 2 || terms == 3 || (terms == 22 && amax_bits != nullptr && amax_rows >= 0));
   SEA_CHECK_ARG(terms == 22 || out_amax == nullptr);
   if (epi) {
     SEA_CHECK_ARG(!epi->addend || epi->ld_addend >= N);
@@ -867,7 +874,7 @@ static int gemm_split_impl(const float* A, int64_t lda, const void* Wp, float* C
   const bool shape16 = g_mfma_shape.load(std::memory_order_relaxed) == 16;
   const bool fused = p.addend || p.gelu_out || p.gelu_grad_of;
   SEA_CHECK_ARG(!(p.a_gelu && (fused || p.a_gelu_grad_of)) && (!p.a_gelu_grad_of || !fused));
-  SEA_CHECK_ARG(!p.a_gelu_grad_of || ((terms == 2 || terms == 22) && (((uintptr_t)p.a_gelu_grad_of) & 15) == 0));
+  SEA_CHECK_ARG(!p.a_gelu_grad_of || ((terms == 1 || terms == 2 || terms == 22) && (((uintptr_t)p.a_gelu_grad_of) & 15) == 0));
   // prologue: 0 none, 1 A * GELU'(t), 2 GELU(A), 3 ReLU gate
   const int pro = p.a_gelu ? 2 : (p.a_gelu_grad_of ? (p.a_gate ? 3 : 1) : 0);
   const hipStream_t st = (hipStream_t)stream;
@@ -889,6 +896,8 @@ static int gemm_split_impl(const float* A, int64_t lda, const void* Wp, float* C
     } else {
       if (pro == 2) SEA_GS_LAUNCH(3, false, false, false, 2); else if (fused) SEA_GS_LAUNCH(3, false, false, true, 0); else SEA_GS_LAUNCH(3, false, false, false, 0);
     }
+  } else if (terms == 1) {   // one bf16 term: the operands of a bf16-autocast GEMM, fp32 in / out (BASELINE configs[3])
+    if (shape16) SEA_GS_PRO(1, true, false); else SEA_GS_PRO(1, false, false);
   } else {
     if (shape16) SEA_GS_PRO(2, true, false); else SEA_GS_PRO(2, false, false);
   }

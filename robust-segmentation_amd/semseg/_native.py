@@ -545,7 +545,7 @@ def wino_conv3x3_cl(x, U, m: int, bias=None, scale=None, relu: bool = False, gat
     T = L.sea_wino_tiles(B, H, W, m)
     V = torch.empty(A2, T, Cin, dtype=torch.float32, device=xs[0].device)
     off = 0
-    use_split = gemm_terms in (2, 3, 22) and Cin % 32 == 0 and T >= 256
+    use_split = gemm_terms in (1, 2, 3, 22) and Cin % 32 == 0 and T >= 256
     # fp16 x 2: one scale word per tile (= per row of the Winograd-domain GEMMs), filled by the transform itself
     v_amax = (torch.zeros(T, dtype=torch.int32, device=xs[0].device)
               if (use_split and gemm_terms == 22 and AMAX_FROM_PRODUCERS) else None)
@@ -714,7 +714,7 @@ def gemm_split_pack(W, trans: bool = False, terms: int = 3) -> PackedWeight:
     L = lib()
     nbytes = L.sea_gemm_split_packed_bytes(N, K, terms)
     if nbytes < 0:
-        raise SeaNativeError(f"gemm_split_pack: unsupported shape N={N} K={K} terms={terms} (K % 32 == 0, terms 2, 3 or 22)")
+        raise SeaNativeError(f"gemm_split_pack: unsupported shape N={N} K={K} terms={terms} (K % 32 == 0, terms 1, 2, 3 or 22)")
     out = torch.empty(G, nbytes, dtype=torch.uint8, device=W.device)
     for g in range(G):
         _check(L.sea_gemm_split_pack(_p(Wb[g]), Wb.stride(1), int(trans), N, K, terms, _p(out[g]), _stream()),
@@ -861,7 +861,7 @@ def gemm_split(A, Wp: PackedWeight, bias=None, relu: bool = False, out=None, ama
     fused = (addend is not None or gelu_out is not None or gelu_grad_of is not None or a_gelu_grad_of is not None
              or a_gelu or amax_mul != 1.0)
     if a_gelu_grad_of is not None and (a_gelu_grad_of.shape != A.shape or a_gelu_grad_of.stride() != A.stride()
-                                       or a_gelu_grad_of.dtype != torch.float32 or Wp.terms not in (2, 22)):
+                                       or a_gelu_grad_of.dtype != torch.float32 or Wp.terms not in (1, 2, 22)):
         raise SeaNativeError("gemm_split: a_gelu_grad_of must be float32 with A's shape and strides (terms 2 or 22)")
     # split-K takes the prologues (applied per slice) and the addend (added by the reduce pass)
     only_pro = gelu_out is None and gelu_grad_of is None

@@ -235,6 +235,13 @@ GEMM_TERMS = int(os.environ.get("SEA_GEMM_TERMS", "22"))
 # Under bf16 autocast (PIR-AT's inner PGD with TRAIN.AMP, BASELINE configs[3]) the decode head's fp32 islands run M8 with
 # TWO terms: 16 significant bits per operand (twice bf16's) at three MFMA products instead of six.
 GEMM_TERMS_AUTOCAST = int(os.environ.get("SEA_GEMM_TERMS_AUTOCAST", "2"))
+# Round 4: the WHOLE attack forward / backward of a frozen model under bf16 autocast as one fp32-I/O island on M8 with ONE
+# bf16 term per operand (SEA_AUTOCAST_ISLAND=model): exactly the operand precision autocast asks for (bf16 operands, fp32
+# accumulate), but with fp32 activations between the layers (no autocast cast kernels, no 16-bit round trips), the fused
+# prologues / epilogues of the fp32 attack path and its host cost.  "head" = round 3's behaviour (only the decode head is an
+# island, with two terms; the trunk's nn.Linear run through autocast's bf16 library GEMMs).
+AUTOCAST_ISLAND = os.environ.get("SEA_AUTOCAST_ISLAND", "model")
+GEMM_TERMS_AUTOCAST_MODEL = int(os.environ.get("SEA_GEMM_TERMS_AUTOCAST_MODEL", "1"))
 # Terms of the INPUT-GRADIENT products.  Default 22 (round 4): fp16 x 2 like the forward -- 22 significant bits per operand,
 # error <= the fp32 GEMM's own -- so that the whole evaluation is fp32-equivalent, as the reference's is.  A gradient
 # operand's rows (pixels) span many orders of magnitude, so its power-of-two scales are PER ROW: exact row maxima
@@ -271,7 +278,7 @@ class _gemm_terms:
 
 
 def _split_ok(x2d, K, terms=None):
-    return ((_terms() if terms is None else terms) in (2, 3, 22) and x2d.is_cuda and x2d.dtype == torch.float32 and x2d.dim() == 2 and K % 32 == 0
+    return ((_terms() if terms is None else terms) in (1, 2, 3, 22) and x2d.is_cuda and x2d.dtype == torch.float32 and x2d.dim() == 2 and K % 32 == 0
             and x2d.stride(1) == 1 and x2d.stride(0) % 4 == 0 and x2d.data_ptr() % 16 == 0
             and x2d.shape[0] >= GEMM_MIN_ROWS and not torch.is_autocast_enabled())
 
@@ -373,7 +380,7 @@ def _linear_frozen(mod_cache, x, w, b, amax=None, out_amax=None):
     """F.linear through M8 when the weights are frozen and the shape qualifies; plain F.linear otherwise.
     ``amax`` / ``out_amax``: device words for the fp16 x 2 mode (see _native.gemm_split): an upper bound of max|x| supplied
     by the producer instead of a pass over x, and a pre-zeroed word that receives max|output|."""
-    if (_terms() in (2, 3, 22) and x.is_cuda and x.dtype == torch.float32 and not w.requires_grad
+    if (_terms() in (1, 2, 3, 22) and x.is_cuda and x.dtype == torch.float32 and not w.requires_grad
             and (b is None or not b.requires_grad) and w.shape[1] % 32 == 0 and not torch.is_autocast_enabled()
             and x.is_contiguous() and x.numel() // x.shape[-1] >= GEMM_MIN_ROWS):
         return _FrozenLinear.apply(x, w, b, mod_cache, amax, out_amax)
@@ -400,7 +407,7 @@ FUSE_PROLOGUE_MAX_NBLOCKS = int(os.environ.get("SEA_FUSE_PRO_NB", "3"))
 def _mlp_fusable(x, w1, b1, w2, b2):
     """both projections of a block's MLP qualify for M8 (frozen weights, fp32 HIP tensor, shapes): the pair runs as two
     GEMMs with GELU, GELU' and the residual add in their epilogues (_FrozenMlp)"""
-    return (FUSE_MLP >= 0 and _terms() in (2, 3, 22) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+    return (FUSE_MLP >= 0 and _terms() in (1, 2, 3, 22) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
             and not torch.is_autocast_enabled() and x.numel() // x.shape[-1] >= GEMM_MIN_ROWS
             and w1.shape[1] % 32 == 0 and w2.shape[1] % 32 == 0 and w2.shape[0] == x.shape[-1]
             and not any(t is not None and t.requires_grad for t in (w1, b1, w2, b2)))
@@ -471,7 +478,7 @@ class _FrozenMlp(torch.autograd.Function):
             mul = {}
         if ctx.fuse & 2:
             gx = N.gemm_split(N.gemm_split(g2, p2, gelu_grad_of=t, groups=nb, **rows), p1, groups=nb, **mul)
-        elif ctx.fuse & 8 and terms in (2, 22) and -(-ctx.w[0].shape[1] // 128) <= FUSE_PROLOGUE_MAX_NBLOCKS:
+        elif ctx.fuse & 8 and terms in (1, 2, 22) and -(-ctx.w[0].shape[1] // 128) <= FUSE_PROLOGUE_MAX_NBLOCKS:
             gx = N.gemm_split(N.gemm_split(g2, p2, groups=nb, **rows), p1, a_gelu_grad_of=t, groups=nb, **mul)
         else:
             gx = N.gemm_split(torch.ops.aten.gelu_backward(N.gemm_split(g2, p2, groups=nb, **rows), t), p1, groups=nb, **mul)
@@ -832,7 +839,7 @@ class _PointwiseRelu(torch.autograd.Function):
     def backward(ctx, gy):
         (y,) = ctx.saved_tensors
         terms = _bwd_terms(ctx.terms)
-        if (RELU_GATE_PROLOGUE and terms in (2, 22) and gy.is_contiguous() and gy.dtype == torch.float32
+        if (RELU_GATE_PROLOGUE and terms in (1, 2, 22) and gy.is_contiguous() and gy.dtype == torch.float32
                 and _split_ok(gy, ctx.w.shape[0], terms)):
             # the ReLU gate is applied to the A tile of the input-gradient GEMM while it is staged: no masked copy of gy
             from .. import _native as N
@@ -1243,7 +1250,17 @@ class UperNetForSemanticSegmentation(nn.Module):
         into its loss kernel (K2u) when a model offers this hook."""
         return self._head_logits(self.backbone(input)), tuple(input.shape[2:])
 
+    def _attack_island(self, input, lbl):
+        """bf16 autocast + frozen weights + eval mode = the attack's forward (PIR-AT inner PGD, BASELINE configs[3])"""
+        return (AUTOCAST_ISLAND == "model" and lbl is None and not self.training and torch.is_autocast_enabled() and input.is_cuda
+                and input.dtype == torch.float32 and GEMM_TERMS != 0
+                and not self.decode_head.classifier.weight.requires_grad
+                and not self.backbone.downsample_layers[1][1].weight.requires_grad)
+
     def forward(self, input, lbl=None):
+        if self._attack_island(input, lbl):
+            with torch.autocast("cuda", enabled=False), _gemm_terms(GEMM_TERMS_AUTOCAST_MODEL):
+                return _up(self.decode_head(self.backbone(input)).contiguous(), input.shape[2:])
         feats = self.backbone(input)
         logits = _up(self._head_logits(feats).contiguous(), input.shape[2:])  # NCHW logits for K2
         loss = None

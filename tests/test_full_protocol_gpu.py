@@ -4,7 +4,7 @@ tools.infer (reference tools/infer.py:332-408).  ~17 s of attack per radius.
 
 Asserted: the L-inf ball and the [0, 1] box of every returned image; the arg-max map and the accuracy the attack hands out
 are those of a fresh forward of the returned image; the worst-case bookkeeping (worst_Acc <= every attack's own aAcc, the
-greedy mIoU <= every attack's own mIoU); the evaluation is bitwise reproducible (two runs, same summary); the captured
+greedy mIoU <= the mIoU of the attack it starts from); the evaluation is bitwise reproducible (two runs, same summary); the captured
 HIP graphs and their activation pools are released (device memory back to where it was); and the wall time per step is
 within 15 % of a short measurement of the same step on this box (the sustained rate of the 900-step run: the chip lowers its
 clock under sustained matrix load).
@@ -83,7 +83,9 @@ def test_configs1_full_sea_3x300_as_written(tmp_path, monkeypatch, eps):
     s = json.load(open(tmp_path / "a.json"))
     assert s["n_images"] == 8 and s["clean"]["aAcc"] == 1.0
     assert 0.0 <= s["worst_Acc"] <= min(s["worst_Acc_indiv"]) + 1e-9
-    assert s["final_miou"] <= min(s["loss-wise_miou"]) + 1e-9
+    # the greedy starts from attack 0 and only accepts swaps that lower the dataset mIoU (worse_only.py:279-334); the two
+    # numbers come from different float widths (float32 tables vs the float64 greedy), hence the 1e-6
+    assert s["final_miou"] <= s["loss-wise_miou"][0] + 1e-6
     assert s["worst_Acc"] < 0.9                               # the attack bites
     # bitwise reproducible at 512 x 512: a second evaluation gives the same numbers, digit for digit -- and leaves nothing
     # behind on the device: the nine runs' captured graphs, their activation pools and per-stream library workspaces are

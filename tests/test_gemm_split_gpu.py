@@ -427,3 +427,35 @@ def test_mfma_shape_16_variants_match_shape_32(N):
         tol = 3e-5 if terms == 2 else 3e-6
         assert (a - b).abs().max().item() <= tol * scale, (terms, name, (a - b).abs().max().item() / scale)
         assert (b.double() - r).abs().max().item() <= tol * scale, (terms, name)
+
+
+def test_one_bf16_term_is_the_bf16_autocast_product_with_fp32_io(N):
+    """terms = 1 (BASELINE configs[3]: the attack under bf16 autocast): exactly the product of the bf16-ROUNDED operands,
+    accumulated in fp32 -- what autocast's GEMM computes, without its 16-bit output rounding"""
+    g = torch.Generator(device="cuda").manual_seed(31)
+    M, K, Nn = 2048, 384, 200
+    A = torch.randn(M, K, generator=g, device="cuda")
+    W = torch.randn(Nn, K, generator=g, device="cuda") / K ** 0.5
+    bias = torch.randn(Nn, generator=g, device="cuda")
+    t = torch.randn(M, K, generator=g, device="cuda")
+    Wp = N.gemm_split_pack(W, terms=1)
+    rb = lambda x: x.bfloat16().double()
+    ref = rb(A) @ rb(W).t() + bias.double()
+    scale = ref.abs().max().item()
+    out = N.gemm_split(A, Wp, bias=bias)
+    assert (out.double() - ref).abs().max().item() <= 2e-6 * scale
+    assert (out.double() - _ref(A, W, bias)).abs().max().item() <= 2e-2 * scale      # bf16 level against the exact product
+    # prologues: applied in fp32 BEFORE the rounding to bf16
+    ref_g = rb(torch.nn.functional.gelu(A)) @ rb(W).t()
+    assert (N.gemm_split(A, Wp, a_gelu=True).double() - ref_g).abs().max().item() <= 2e-6 * ref_g.abs().max().item()
+    ref_d = rb(A * torch.ops.aten.gelu_backward(torch.ones_like(t), t)) @ rb(W).t()
+    assert (N.gemm_split(A, Wp, a_gelu_grad_of=t).double() - ref_d).abs().max().item() <= 3e-6 * ref_d.abs().max().item()
+    ref_r = rb(torch.where(t > 0, A, torch.zeros_like(A))) @ rb(W).t()
+    assert (N.gemm_split(A, Wp, a_relu_gate=t).double() - ref_r).abs().max().item() <= 2e-6 * ref_r.abs().max().item()
+    # batched (the Winograd-domain products) and bitwise reproducible
+    A3 = torch.randn(5, 300, 64, generator=g, device="cuda")
+    W3 = torch.randn(5, 130, 64, generator=g, device="cuda")
+    o3 = N.gemm_split(A3, N.gemm_split_pack(W3, terms=1))
+    r3 = torch.einsum("gmk,gnk->gmn", rb(A3), rb(W3))
+    assert (o3.double() - r3).abs().max().item() <= 2e-6 * r3.abs().max().item()
+    assert torch.equal(o3, N.gemm_split(A3, N.gemm_split_pack(W3, terms=1)))

@@ -321,15 +321,6 @@ int sea_nhwc_to_nchw(const float* in, const float* scale, const float* residual,
  * pixels (B,H,W,C) channels_last <-> patch rows (B*H/2*W/2, 4*C) in (di, dj, c) order, so that the convolution is one GEMM
  * (bitwise reproducible, unlike the MIOpen kernel it replaces).  inverse != 0: patches -> pixels (the backward). */
 int sea_patch2x2(const float* src, float* dst, int B, int H, int W, int C, int inverse, void* stream);
-/* M9: the decode head's final 1x1 convolution for small class counts (cls <= 32; reference
- * semseg/models/uperforseg.py:262 `classifier`), frozen weights, as HBM-bound streaming kernels instead of a skinny GEMM:
- *   sea_classifier_fwd: out (B, cls, P) NCHW logits = bias[k] + sum_c W[k][c] * y[b][p][c], y dense channels_last rows
- *                       (B * P rows of Cin floats, Cin % 32 == 0, 16-byte aligned), W (cls, Cin) row-major;
- *   sea_classifier_bwd: gy (B, P, Cin) = sum_k g[b][k][p] * W[k][c], g (B, cls, P).
- * fp32 FMA chains in a fixed order (bitwise reproducible). */
-int sea_classifier_fwd(const float* y, const float* W, const float* bias, float* out, int B, int P, int Cin, int cls,
-                       void* stream);
-int sea_classifier_bwd(const float* g, const float* W, float* gy, int B, int P, int Cin, int cls, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * M7  fp32 multi-head attention on the matrix cores (v_mfma_f32_32x32x2_f32), flash formulation.

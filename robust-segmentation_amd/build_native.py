@@ -42,7 +42,6 @@ SOURCES = [
     ("attention.hip", []),
     ("attention_bf16.hip", []),
     ("gemm_split.hip", []),
-    ("classifier_kernels.hip", []),
     ("greedy_host.cpp", ["-ffp-contract=off"]),
     ("api_misc.cpp", []),
 ]

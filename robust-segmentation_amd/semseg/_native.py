@@ -67,8 +67,6 @@ _SIGS = {
     "sea_upsample_bilinear_nhwc_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i64, _vp]),
     "sea_upsample_bilinear_nhwc_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i64, _vp]),
     "sea_patch2x2": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "sea_classifier_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "sea_classifier_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sea_attention_fwd": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "sea_attention_bwd": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                _i64, _i64, _i64, _vp]),
@@ -629,29 +627,6 @@ def unpatch2x2(rows, B, H, W):
     out = torch.empty(B, H, W, Cc, dtype=torch.float32, device=rows.device)
     _check(lib().sea_patch2x2(_p(rows), _p(out), B, H, W, Cc, 1, _stream()), "sea_patch2x2")
     return out
-
-
-# ------------------------------------------------------------------------------------------------ M9
-def classifier_fwd(y, w2d, bias):
-    """NCHW logits (B, cls, H, W) of a dense channels_last y (B, Cin, H, W) for cls <= 32 (frozen 1x1 classifier)"""
-    _dev(y, w2d, bias)
-    B, Cin, H, W = y.shape
-    cls = w2d.shape[0]
-    if cl_pixel_stride(y) != Cin or y.dtype != torch.float32 or cls > 32 or Cin % 32 or w2d.shape[1] != Cin:
-        raise SeaNativeError("classifier_fwd: dense channels_last float32 input, cls <= 32, Cin % 32 == 0 expected")
-    out = torch.empty(B, cls, H, W, dtype=torch.float32, device=y.device)
-    _check(lib().sea_classifier_fwd(_p(y), _p(_f32c(w2d)), _p(None if bias is None else _f32c(bias)), _p(out), B, H * W, Cin, cls,
-                                    _stream()), "sea_classifier_fwd")
-    return out
-
-
-def classifier_bwd(g, w2d, Cin):
-    """gradient w.r.t. the channels_last input of classifier_fwd: (B, Cin, H, W) channels_last from g (B, cls, H, W)"""
-    _dev(g, w2d)
-    B, cls, H, W = g.shape
-    gy = torch.empty(B, Cin, H, W, dtype=torch.float32, device=g.device, memory_format=torch.channels_last)
-    _check(lib().sea_classifier_bwd(_p(_f32c(g)), _p(_f32c(w2d)), _p(gy), B, H * W, Cin, cls, _stream()), "sea_classifier_bwd")
-    return gy
 
 
 # ------------------------------------------------------------------------------------------------ M7

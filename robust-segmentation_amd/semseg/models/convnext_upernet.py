@@ -1130,9 +1130,6 @@ class PyramidPooling(nn.Module):
         return [_up(p, x.shape[2:]) for p in self.pooled(x)]
 
 
-USE_HIP_CLASSIFIER = os.environ.get("SEA_HIP_CLASSIFIER", "1") != "0"
-
-
 class _ClassifierGemm(torch.autograd.Function):
     """logits (B,cls,H,W) NCHW = W (cls,Cin) . y_b^T for a dense channels_last y (B,Cin,H,W), frozen weights.
     The backward computes the input gradient directly in y's channels_last layout, g_b^T (P,cls) . W (cls,Cin):
@@ -1142,24 +1139,16 @@ class _ClassifierGemm(torch.autograd.Function):
     @_fp32_fwd
     def forward(ctx, y, w2d, bias):
         B, Cin, H, W = y.shape
-        ctx.w2d, ctx.shape = w2d, (B, Cin, H, W)
-        ctx.stream = USE_HIP_CLASSIFIER and w2d.shape[0] <= 32 and Cin % 32 == 0 and y.data_ptr() % 16 == 0
-        if ctx.stream:
-            # M9: 21 classes are HBM-bound streaming work (268 MB against 2.9 GFLOP at B = 8, 128^2), not a GEMM
-            from .. import _native as N
-            return N.classifier_fwd(y, w2d, bias)
         out = torch.matmul(w2d, y.permute(0, 2, 3, 1).reshape(B, H * W, Cin).transpose(1, 2))
         if bias is not None:
             out += bias.view(1, -1, 1)
+        ctx.w2d, ctx.shape = w2d, (B, Cin, H, W)
         return out.view(B, w2d.shape[0], H, W)
 
     @staticmethod
     @_fp32_bwd
     def backward(ctx, g):
         B, Cin, H, W = ctx.shape
-        if ctx.stream:
-            from .. import _native as N
-            return N.classifier_bwd(g.contiguous(), ctx.w2d, Cin), None, None
         gy = torch.matmul(g.reshape(B, g.shape[1], H * W).transpose(1, 2), ctx.w2d)      # (B, P, Cin) contiguous
         return gy.view(B, H, W, Cin).permute(0, 3, 1, 2), None, None
 

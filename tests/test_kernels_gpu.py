@@ -1159,30 +1159,3 @@ def test_patch_conv_2x2_matches_conv2d_and_is_deterministic(N):
         xn = x.detach().permute(0, 2, 3, 1).contiguous()
         ref = xn.reshape(2, hw // 2, 2, hw // 2, 2, cin).permute(0, 1, 3, 2, 4, 5).reshape(-1, 4 * cin)
         assert torch.equal(N.patch2x2(xn), ref) and torch.equal(N.unpatch2x2(ref.contiguous(), 2, hw, hw), xn)
-
-
-@pytest.mark.parametrize("B,Cin,H,W,cls", [(2, 512, 32, 32, 21), (1, 512, 15, 13, 21), (3, 64, 8, 40, 5), (2, 768, 16, 16, 32),
-                                           (8, 512, 128, 128, 21)])
-def test_streaming_classifier_matches_the_gemm(B, Cin, H, W, cls):
-    """M9: the decode head's final 1x1 convolution at small class counts as streaming kernels (sea_classifier_fwd / _bwd)
-    against the float64 product; the forward output IS the NCHW logit tensor, the backward output the channels_last gradient
-    (reference semseg/models/uperforseg.py:262); bitwise reproducible"""
-    from semseg import _native as N
-    g = torch.Generator(device="cuda").manual_seed(B * 1000 + cls)
-    y = torch.randn(B, Cin, H, W, generator=g, device="cuda").contiguous(memory_format=torch.channels_last)
-    w = torch.randn(cls, Cin, generator=g, device="cuda") * 0.05
-    b = torch.randn(cls, generator=g, device="cuda")
-    out = N.classifier_fwd(y, w, b)
-    ref = torch.einsum("kc,bchw->bkhw", w.double(), y.double()) + b.double().view(1, -1, 1, 1)
-    assert out.shape == (B, cls, H, W) and out.is_contiguous()
-    lib = torch.nn.functional.conv2d(y, w.view(cls, Cin, 1, 1), b)
-    scale = ref.abs().max().item()
-    e_own, e_lib = (out.double() - ref).abs().max().item() / scale, (lib.double() - ref).abs().max().item() / scale
-    assert e_own <= max(4 * e_lib, 2e-6), (e_own, e_lib)
-    assert torch.equal(out, N.classifier_fwd(y, w, b))
-    go = torch.randn(B, cls, H, W, generator=g, device="cuda")
-    gy = N.classifier_bwd(go, w, Cin)
-    gref = torch.einsum("bkhw,kc->bchw", go.double(), w.double())
-    assert gy.shape == (B, Cin, H, W) and gy.is_contiguous(memory_format=torch.channels_last)
-    assert (gy.double() - gref).abs().max().item() <= 2e-6 * gref.abs().max().item()
-    assert torch.equal(gy, N.classifier_bwd(go, w, Cin))

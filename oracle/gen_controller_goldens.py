@@ -171,5 +171,67 @@ def main():
             net_seed=np.int64(C + 40 + seed), min_gap=np.float64(gap), x_adv=xa, acc=acc)))
 
 
+def real_model(n_iter=40, loss="mask-ce-bal", threads=2):
+    """g13_ctrl_real_upernet_t_*: the reference's apgd_largereps on the REAL UperNet-ConvNeXt-T at 512 x 512 with n_iter = 40
+    (stages 12 / 12 / 16: long enough for the product's HIP-graph replay in every stage), eps 4/255.  Stored: checksums of
+    all 43 iterates, sign(g) planes, per-evaluation losses / counts / near-tie counts, the returned image's checksum."""
+    from gen_goldens import _build_state_dict, _reference_model
+    torch.set_num_threads(threads)
+    C = 21
+    sd = _build_state_dict("upernet", "ConvNeXt-T_CVST", C)
+    ref = _reference_model("upernet", "ConvNeXt-T_CVST", C, sd)
+    os.chdir(REF)
+    import semseg.attacker as A
+    from semseg.utils.utils import VOC_WTS
+    w = torch.tensor(VOC_WTS)
+    x = torch.rand(2, 3, 512, 512, generator=torch.Generator().manual_seed(1234))[:1].clone()
+    with torch.no_grad():
+        y = ref(x).max(1)[1]
+    mask_bg = (y != -1).float()
+
+    def stats(logits):
+        with torch.no_grad():
+            li = A.pixel_to_img_loss(A.criterion_dict[loss](logits, y, w), mask_bg)
+            ce = A.pixel_to_img_loss(A.criterion_dict["ce-avg"](logits, y), mask_bg)
+            top2 = logits.topk(2, dim=1)[0]
+            near = ((top2[:, 0] - top2[:, 1]) < 2e-4 * logits.abs().max()).flatten(1).sum(1)
+            n_correct = (logits.max(1)[1] == y).flatten(1).sum(1)
+        return dict(li=li.clone(), ce=ce.clone(), n_correct=n_correct, n_near=near)
+
+    rec = Recorder(ref, stats).eval()
+    torch.manual_seed(4321)
+    import time
+    t0 = time.time()
+    with contextlib.redirect_stdout(io.StringIO()):
+        xa, _, acc = A.apgd_largereps(rec, x.clone(), y, w, norm="Linf", eps=4.0 / 255, n_iter=n_iter, n_restarts=1, use_rs=True,
+                                      loss=loss, verbose=False, track_loss="ce-avg", log_path=None, num_classes=C, early_stop=True)
+    n_iters = [int(0.3 * n_iter), int(0.3 * n_iter)]
+    n_iters.append(n_iter - sum(n_iters))
+    assert len(rec.evals) == n_iter + 3, len(rec.evals)
+    gap = smallest_gaps(torch.stack([e["ce"] for e in rec.evals]), n_iters)
+    out = dict(y=y.to(torch.uint8), eps=np.float64(4.0 / 255), n_iter=np.int64(n_iter), seed=np.int64(4321),
+               n_evals=np.int64(len(rec.evals)), min_gap=np.float64(gap), acc=acc, x_adv_chk=checksum(xa),
+               seconds=np.float64(time.time() - t0))
+    out["chk"] = torch.stack([e["chk"] for e in rec.evals])
+    for k in ("li", "ce", "n_correct", "n_near"):
+        out[k] = torch.stack([e[k] for e in rec.evals])
+    out["has_grad"] = np.array([e["g"] is not None for e in rec.evals])
+    for j, e in enumerate(rec.evals):
+        if e["g"] is not None:
+            g = e["g"].flatten()
+            out[f"e{j}_neg"] = np.packbits((g < 0).numpy())
+            out[f"e{j}_zero"] = np.packbits((g == 0).numpy())
+    name = f"g13_ctrl_real_upernet_t_{loss}_{n_iter}"
+    np.savez_compressed(os.path.join(OUT, name + ".npz"),
+                        **{k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in out.items()})
+    print("wrote", name, os.path.getsize(os.path.join(OUT, name + ".npz")) // 1024, "KiB; smallest relative gap of a loss "
+          f"comparison {gap:.2e}; acc {acc.tolist()}; {time.time() - t0:.0f}s", flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    if "--real" in sys.argv:
+        # python oracle/gen_controller_goldens.py --real [loss [n_iter]]
+        rest = [a for a in sys.argv[1:] if a != "--real"]
+        real_model(loss=rest[0] if rest else "mask-ce-bal", n_iter=int(rest[1]) if len(rest) > 1 else 40)
+    else:
+        main()

@@ -128,3 +128,37 @@ def test_apgd_largereps_controller_exact_on_the_real_models(case, loss):
     # accuracy of the returned image: the reference's, up to its near-tie pixels (arg-max rounding)
     e = int(g["final_eval"])
     assert abs(float(acc.item()) - float(g["acc"].item())) <= int(g[f"e{e}_n_near"]) / (512.0 * 512.0) + 1e-7
+
+
+@pytest.mark.parametrize("loss", ["mask-ce-bal", "js-avg"])
+def test_apgd_largereps_controller_exact_on_upernet_t_with_graph_replay(loss):
+    """UperNet-ConvNeXt-T at 512 x 512, apgd_largereps(n_iter = 40) = stages 12 / 12 / 16: every stage is long enough for the
+    product's HIP-graph replay, so THIS test runs the captured graphs (K1 in place, device-side loop index and checkpoint
+    table, K7 / K4 inside graph B) on the real model against the reference's 43 iterates, bit for bit.  The product's losses
+    on the real model differ from the reference's by up to 7e-5 relative (teacher-forced measurements), so a decision of
+    the reference that hangs on a comparison closer than that could legitimately go the other way: the fixture records the
+    smallest gap of the run, printed here."""
+    name = f"g13_ctrl_real_upernet_t_{loss}_40"
+    if not os.path.exists(os.path.join(GOLDEN, name + ".npz")):
+        pytest.skip("no real-model controller fixture for this loss (oracle/gen_controller_goldens.py --real <loss>)")
+    from real_models import build_model
+    from semseg import attacker as A
+    from semseg.utils.utils import VOC_WTS
+    g = load_golden(name)
+    x = T.image()
+    n = int(g["n_evals"])
+    model = build_model("upernet", "ConvNeXt-T_CVST", 21).cuda()
+    inj = T.SignInjector(model, T.sign_planes(g, x.shape, "cuda")).eval()
+    torch.manual_seed(int(g["seed"]))
+    noises = [torch.rand_like(x) for _ in range(3)]
+    assert A.USE_HIP_GRAPH and min(A.largereps_schedule(int(g["n_iter"]), 1.0)[0]) >= A.GRAPH_MIN_ITER
+    xa, _, acc = A.apgd_largereps(inj, x.cuda().clone(), g["y"].long().cuda(), torch.tensor(VOC_WTS).cuda(), norm="Linf",
+                                  eps=float(g["eps"]), n_iter=int(g["n_iter"]), n_restarts=1, use_rs=True, loss=loss,
+                                  verbose=False, track_loss="ce-avg", log_path=None, num_classes=21, early_stop=True, noises=noises)
+    ties = _near_ties(g["ce"], A.largereps_schedule(int(g["n_iter"]), 1.0)[0])
+    print(f"\n[{name}] smallest relative gap of a reference loss comparison {float(g['min_gap']):.2e}; within 1e-4 of a tie: "
+          f"{ties or 'none'}")
+    _compare_checksums(name, inj, g["chk"], n)
+    assert torch.equal(T.checksum(xa.cpu()), g["x_adv_chk"]), "the returned image is not the reference's"
+    last = n - 1
+    assert abs(float(acc.item()) - float(g["acc"].item())) <= int(g["n_near"][last].max()) / (512.0 * 512.0) + 1e-7

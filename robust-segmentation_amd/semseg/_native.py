@@ -882,6 +882,14 @@ def gemm_split(A, Wp: PackedWeight, bias=None, relu: bool = False, out=None, ama
                                                 addend.stride(0) if addend is not None else 0, int(relu), _p(O3), O3.stride(1),
                                                 _p(out_amax) if Wp.terms == 22 else None, _stream()), "sea_gemm_splitk_reduce")
             return out
+    if addend is not None and (a_gelu or a_gelu_grad_of is not None):
+        # a prologue and an addend only travel together through split-K (the reduce pass adds); when this product does not
+        # split (few K blocks, unaligned addend, batched weights) the C ABI rejects the pair: add separately instead
+        out = gemm_split(A, Wp, bias=bias, relu=False, out=out, amax=amax, out_amax=None, amax_rows=amax_rows, groups=groups,
+                         a_gelu_grad_of=None if gate else a_gelu_grad_of, a_gelu=a_gelu,
+                         a_relu_gate=a_gelu_grad_of if gate else None, row_amax=row_amax, amax_mul=amax_mul)
+        out += addend
+        return torch.relu_(out) if relu else out
     if fused:
         epi = _GemmEpilogue()
         if addend is not None:

@@ -460,3 +460,20 @@ def test_one_bf16_term_is_the_bf16_autocast_product_with_fp32_io(N):
     r3 = torch.einsum("gmk,gnk->gmn", rb(A3), rb(W3))
     assert (o3.double() - r3).abs().max().item() <= 2e-6 * r3.abs().max().item()
     assert torch.equal(o3, N.gemm_split(A3, N.gemm_split_pack(W3, terms=1)))
+
+
+@pytest.mark.parametrize("terms", [22, 2])
+def test_prologue_with_addend_on_a_product_that_does_not_split(N, terms):
+    """GELU-prologue + residual addend travel together only through split-K (the reduce pass adds).  On a product whose
+    tile grid is large enough NOT to split, the pair used to reach sea_gemm_split_fused, which rejects it (ADVICE, round 3):
+    gemm_split now adds the residual separately; same numbers as the two steps done by hand"""
+    g = torch.Generator(device="cuda").manual_seed(41)
+    M, K, Nn = 16384, 128, 512           # 128 x 4 tiles >= KSPLIT_BELOW: no split-K
+    assert N._ksplit(M, Nn, K) == 1
+    A = torch.randn(M, K, generator=g, device="cuda")
+    W = torch.randn(Nn, K, generator=g, device="cuda") / K ** 0.5
+    res = torch.randn(M, Nn, generator=g, device="cuda")
+    Wp = N.gemm_split_pack(W, terms=terms)
+    got = N.gemm_split(A, Wp, a_gelu=True, addend=res, groups=4)
+    want = N.gemm_split(A, Wp, a_gelu=True, groups=4) + res
+    assert torch.equal(got, want)

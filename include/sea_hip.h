@@ -416,6 +416,8 @@ typedef struct SeaGemmEpilogue {
   float a_amax_mul;            /* terms 22, > 0: the amax_bits words bound max|A| only after multiplication by this constant (a
                                 * producer-side per-row bound carried through the GEMM in between: rowmax(g) * max_n ||W_n||_1,
                                 * times max|GELU'| = 1.13 for the a_gelu_grad_of prologue); 0 = 1: the words as they are */
+  const float* a_amax_mul_dev; /* the same constant as ONE float in device memory (takes precedence when non-NULL): a caller whose
+                                * weights change every step (PIR-AT) derives it on the device without a host round trip */
 } SeaGemmEpilogue;
 int sea_gemm_split_fused(const float* A, int64_t lda, const void* Wp, float* C, int64_t ldc, const float* bias, int relu, int M,
                          int N, int K, int terms, int batch, int64_t strideA, int64_t strideW_bytes, int64_t strideC,

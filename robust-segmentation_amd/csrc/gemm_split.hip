@@ -114,6 +114,7 @@ struct GemmSplitArgs {
   int amax_rows;
   float amax_mul;              // fp16 x 2 only: the words bound max|A| / amax_mul (a producer-side bound times a constant of the
                                // consumer: ||W||_1 of the GEMM in between, max|GELU'|); 1 = the words as they are
+  const float* amax_mul_dev;   // the same constant in device memory (no host round trip when the weights change every step)
   const float* w_inv;          // fp16 x 2 only: per-column inverse weight scale
   uint32_t* out_amax;          // optional: atomic max of the float bits of |C| (pre-zeroed word), for a consumer GEMM
   // fused epilogue extras (sea_gemm_split_fused): all optional
@@ -183,7 +184,8 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(const GemmSplitArgs 
       row = row < M ? row : M - 1;
       float sc, inv;
       uint32_t word = p.amax_bits[p.amax_rows > 0 ? row / p.amax_rows : 0];
-      if (p.amax_mul != 1.f) word = __float_as_uint(__uint_as_float(word) * p.amax_mul) & 0x7fffffffu;
+      const float mul = p.amax_mul_dev ? *p.amax_mul_dev : p.amax_mul;
+      if (mul != 1.f) word = __float_as_uint(__uint_as_float(word) * mul) & 0x7fffffffu;
       pow2_scale(word, sc, inv);
       row_sc[tid] = sc;
       row_inv[tid] = inv;
@@ -866,6 +868,7 @@ static int gemm_split_impl(const float* A, int64_t lda, const void* Wp, float* C
   p.a_gelu = epi ? epi->a_gelu : 0;
   p.a_gate = epi ? epi->a_gate : 0;
   p.amax_mul = (epi && epi->a_amax_mul > 0.f) ? epi->a_amax_mul : 1.f;
+  p.amax_mul_dev = epi ? epi->a_amax_mul_dev : nullptr;
   p.w_inv = terms == 22 ? (const float*)((const char*)Wp + (int64_t)(K / GS_BK) * 2 * gs_npad(N) * GS_BK * 2) : nullptr;
   const dim3 grid(p.per_xcd * 8), block(256);
   // MFMA shape: 32x32x16 fragments (default) or 16x16x32 (SEA_GEMM_SHAPE=16 / sea_gemm_split_mfma_shape(16)): the chip holds a

@@ -802,7 +802,7 @@ def ksplit_workspace_pin(device):
 class _GemmEpilogue(C.Structure):       # SeaGemmEpilogue of include/sea_hip.h
     _fields_ = [("addend", C.c_void_p), ("ld_addend", C.c_int64), ("stride_addend", C.c_int64),
                 ("gelu_out", C.c_void_p), ("gelu_grad_of", C.c_void_p), ("a_gelu_grad_of", C.c_void_p), ("a_gate", C.c_int), ("a_gelu", C.c_int),
-                ("a_amax_mul", C.c_float)]
+                ("a_amax_mul", C.c_float), ("a_amax_mul_dev", C.c_void_p)]
 
 
 def _amax_words(A3, M, K, G, sA, groups, per_row=False):
@@ -857,12 +857,16 @@ def gemm_split(A, Wp: PackedWeight, bias=None, relu: bool = False, out=None, ama
     if amax is not None and (amax.dtype != torch.int32 or not amax.is_contiguous()
                              or amax.numel() < (-(-M // amax_rows) if amax_rows > 0 else 1)):
         raise SeaNativeError("gemm_split: amax must hold one int32 word per amax_rows rows")
-    amax_mul = float(amax_mul) if Wp.terms == 22 else 1.0
+    # a Python float, or ONE float32 in device memory (derived on the device: no host round trip)
+    mul_dev = amax_mul if (torch.is_tensor(amax_mul) and Wp.terms == 22) else None
+    if mul_dev is not None and (mul_dev.dtype != torch.float32 or mul_dev.numel() != 1 or mul_dev.device != A.device):
+        raise SeaNativeError("gemm_split: a tensor amax_mul must be one float32 on A's device")
+    amax_mul = float(amax_mul) if (Wp.terms == 22 and mul_dev is None) else 1.0
     fused = (addend is not None or gelu_out is not None or gelu_grad_of is not None or a_gelu_grad_of is not None
-             or a_gelu or amax_mul != 1.0)
+             or a_gelu or amax_mul != 1.0 or mul_dev is not None)
     if a_gelu_grad_of is not None and (a_gelu_grad_of.shape != A.shape or a_gelu_grad_of.stride() != A.stride()
                                        or a_gelu_grad_of.dtype != torch.float32 or Wp.terms not in (1, 2, 22)):
-        raise SeaNativeError("gemm_split: a_gelu_grad_of must be float32 with A's shape and strides (terms 2 or 22)")
+        raise SeaNativeError("gemm_split: a_gelu_grad_of must be float32 with A's shape and strides (terms 1, 2 or 22)")
     # split-K takes the prologues (applied per slice) and the addend (added by the reduce pass)
     only_pro = gelu_out is None and gelu_grad_of is None
     add_ok = addend is None or (addend.dim() == 2 and addend.shape == O3.shape[1:] and addend.stride(1) == 1
@@ -876,7 +880,7 @@ def gemm_split(A, Wp: PackedWeight, bias=None, relu: bool = False, out=None, ama
             shape, strides = (S, M, K // S), (K // S, A3.stride(1), 1)
             gemm_split(A3[0].as_strided(shape, strides), Wp.k_slices(S), out=part, amax=amax, amax_rows=amax_rows,
                        a_gelu_grad_of=None if (a_gelu_grad_of is None or gate) else a_gelu_grad_of.as_strided(shape, strides),
-                       a_gelu=a_gelu, amax_mul=amax_mul,
+                       a_gelu=a_gelu, amax_mul=mul_dev if mul_dev is not None else amax_mul,
                        **({"a_relu_gate": a_gelu_grad_of.as_strided(shape, strides)} if gate else {}))
             _check(lib().sea_gemm_splitk_reduce(_p(part), S, M, Wp.N, _p(bias), _p(addend),
                                                 addend.stride(0) if addend is not None else 0, int(relu), _p(O3), O3.stride(1),
@@ -887,7 +891,8 @@ def gemm_split(A, Wp: PackedWeight, bias=None, relu: bool = False, out=None, ama
         # split (few K blocks, unaligned addend, batched weights) the C ABI rejects the pair: add separately instead
         out = gemm_split(A, Wp, bias=bias, relu=False, out=out, amax=amax, out_amax=None, amax_rows=amax_rows, groups=groups,
                          a_gelu_grad_of=None if gate else a_gelu_grad_of, a_gelu=a_gelu,
-                         a_relu_gate=a_gelu_grad_of if gate else None, row_amax=row_amax, amax_mul=amax_mul)
+                         a_relu_gate=a_gelu_grad_of if gate else None, row_amax=row_amax,
+                         amax_mul=mul_dev if mul_dev is not None else amax_mul)
         out += addend
         return torch.relu_(out) if relu else out
     if fused:
@@ -908,6 +913,7 @@ def gemm_split(A, Wp: PackedWeight, bias=None, relu: bool = False, out=None, ama
             epi.a_gate = int(gate)
         epi.a_gelu = int(bool(a_gelu))
         epi.a_amax_mul = amax_mul if amax_mul != 1.0 else 0.0
+        epi.a_amax_mul_dev = mul_dev.data_ptr() if mul_dev is not None else None
         if Wp.terms == 22 and amax is None:
             amax, amax_rows = _amax_words(A3, M, K, G, sA, groups, row_amax)
         _check(lib().sea_gemm_split_fused(_p(A3), A3.stride(1), _p(Wp.data), _p(O3), O3.stride(1), _p(bias), int(relu), M, Wp.N,

@@ -344,14 +344,15 @@ def _linear_bound_word(in_word, w, b, cache):
     return cache["lin_bound"]
 
 
-def _l1_bound(w, cache, dim):
-    """max over the other dim of sum_dim |w| as a Python float, rounded up (one device sync per weight, cached until the
-    weight changes).  For w of shape (N, K): dim = 0 bounds the input-gradient product u = g w row by row,
+def _l1_bound(w, cache, dim, factor=1.0):
+    """ONE float32 in device memory: factor * max over the other dim of sum_dim |w|, rounded up (cached until the weight
+    changes; derived on the device, so a weight that changes every step -- PIR-AT -- costs no host round trip).  For w of
+    shape (N, K): dim = 0 bounds the input-gradient product u = g w row by row,
     |u[r][k]| = |sum_n g[r][n] w[n][k]| <= rowmax(g[r]) * max_k sum_n |w[n][k]|; dim = 1 bounds the forward product x w^T."""
-    key = (_tkey(w), dim)
+    key = (_tkey(w), dim, factor)
     if cache.get("l1_key") != key:
         with torch.no_grad():
-            cache.update(l1_key=key, l1=float(w.detach().abs().sum(dim).max().item()) * (1.0 + 1e-6))
+            cache.update(l1_key=key, l1=(w.detach().abs().sum(dim).max() * (factor * (1.0 + 1e-6))).float().reshape(1))
     return cache["l1"]
 
 
@@ -473,7 +474,7 @@ class _FrozenMlp(torch.autograd.Function):
         if terms == 22:
             words, _ = N._amax_words(g2.unsqueeze(0), g2.shape[0], g2.shape[1], 1, 0, nb, per_row=True)
             rows = dict(amax=words, amax_rows=1)
-            mul = dict(amax_mul=_l1_bound(ctx.w[1], ctx.caches[1], dim=0) * 1.13, **rows)
+            mul = dict(amax_mul=_l1_bound(ctx.w[1], ctx.caches[1], dim=0, factor=1.13), **rows)
         else:
             mul = {}
         if ctx.fuse & 2:

@@ -362,12 +362,16 @@ def test_fp16x2_row_bound_carried_through_a_gemm(N):
     gy = torch.randn(R, C, generator=g, device="cuda") * torch.exp2(torch.randint(-40, 4, (R, 1), generator=g, device="cuda").float())
     t = torch.randn(R, 4 * C, generator=g, device="cuda")
     words, _ = N._amax_words(gy.unsqueeze(0), R, C, 1, 0, 1, per_row=True)
-    mul = M._l1_bound(W2, {}, dim=0) * 1.13
+    mul_dev = M._l1_bound(W2, {}, dim=0, factor=1.13)        # one float32 on the device (what the model hands over)
+    mul = float(mul_dev.item())
     u = N.gemm_split(gy, N.gemm_split_pack(W2, trans=True, terms=22), amax=words, amax_rows=1)
     loose = (words.view(torch.float32) * mul) / (u * torch.ops.aten.gelu_backward(torch.ones_like(u), t)).abs().amax(1)
     assert loose.min() >= 1.0, loose.min()                # it IS a bound
     print(f"row bound / realised row maximum: median {loose.median():.1f}, max {loose.max():.1f}")
     got = N.gemm_split(u, N.gemm_split_pack(W1, trans=True, terms=22), a_gelu_grad_of=t, amax=words, amax_rows=1, amax_mul=mul)
+    got_dev = N.gemm_split(u, N.gemm_split_pack(W1, trans=True, terms=22), a_gelu_grad_of=t, amax=words, amax_rows=1,
+                           amax_mul=mul_dev)
+    assert torch.equal(got, got_dev)                          # host float and device float: the same scales
     ref = (u.double() * torch.ops.aten.gelu_backward(torch.ones_like(u), t).double()) @ W1.double()
     lib = (u * torch.ops.aten.gelu_backward(torch.ones_like(u), t)) @ W1
     rs = ref.abs().amax(1, keepdim=True)

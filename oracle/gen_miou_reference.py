@@ -61,11 +61,18 @@ def main():
     ap.add_argument("--n-iter", type=int, default=100)
     ap.add_argument("--threads", type=int, default=4)
     ap.add_argument("--limit", type=int, default=PART, help="images of the part to run (timing probes)")
+    ap.add_argument("--no-mkldnn", action="store_true",
+                    help="run the reference with oneDNN switched off (torch.backends.mkldnn.enabled = False): every convolution "
+                         "then goes through PyTorch's native im2col + BLAS path, i.e. ANOTHER valid fp32 arithmetic in every "
+                         "layer (logits differ by ~8e-7 relative) -- the re-run that is comparable to what a different "
+                         "implementation such as the device path changes; use with --tag _nomkldnn")
     ap.add_argument("--tag", default="", help="file-name suffix of a RE-RUN of an existing part with another thread count "
                     "(reference-vs-reference noise floor, tests/test_miou_claim_gpu.py), e.g. --threads 3 --tag _t3")
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(args.threads)
+    if args.no_mkldnn:
+        torch.backends.mkldnn.enabled = False
 
     from gen_goldens import _build_state_dict, _reference_model
     sd = _build_state_dict("upernet", "ConvNeXt-T_CVST", C)
@@ -170,7 +177,7 @@ def main():
             unions=st["run_union_imwise"].to(torch.int32).numpy(), correct=correct.to(torch.int32).numpy(),
             worst_Acc=np.float64(ev.saveDict["worst_Acc"]), final_miou=np.float64(ev.saveDict["final_miou"]),
             worst_Acc_indiv=ev.saveDict["worst_Acc_indiv"].numpy(), seconds=np.float64(dt),
-            threads=np.int64(args.threads))
+            threads=np.int64(args.threads), mkldnn=np.int64(0 if args.no_mkldnn else 1))
         print(f"wrote {name}: worst aAcc {100 * ev.saveDict['worst_Acc']:.4f} %  worst mIoU "
               f"{100 * ev.saveDict['final_miou']:.4f} %  {dt:.0f}s", flush=True)
 

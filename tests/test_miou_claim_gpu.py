@@ -33,9 +33,12 @@ What is asserted (fixed in advance; no band is widened after a failure):
                 is the one that perturbs every layer like another implementation does, not the thread-count one.
   3 x 300       where a part at the protocol's full length is committed (`*_it300`): the same assertions as its radius.
 
-The device run is made bitwise reproducible for this test (the 3x3 convolutions on the 4x4 and 8x8 maps of a 128x128 input
-go through the Winograd path instead of a MIOpen kernel that accumulates with atomics), so the test's outcome is a function
-of the committed fixtures and the code, not of chance.  Measured values: profiles/r4_miou_vs_reference.log.
+At 128 x 128 the device run is NOT bitwise reproducible (at 512 x 512 it is): the 3x3 convolutions on the 4x4 and 8x8 maps are
+sent through the Winograd path here instead of a MIOpen kernel that accumulates with atomics, which removes the largest
+source, but the library GEMMs of the layers with fewer than 1024 rows still differ in the last bit from run to run, and the
+attack amplifies that: three runs of this test in round 4 gave a device worst-case aAcc of 18.179 / 18.191 / 18.200 % at
+eps 8 (44.998 / 44.994 % at eps 4).  The asserted bands leave room for that: see the measured values in
+profiles/r4_miou_vs_reference.log.
 """
 import numpy as np
 import pytest
@@ -53,7 +56,7 @@ def model():
     m = UperNetForSemanticSegmentation("ConvNeXt-T_CVST", R.C, None).eval().cuda()
     with torch.no_grad():
         m.decode_head.classifier.bias.copy_(R.bias().cuda())
-    old, M.WINOGRAD_MIN_PIXELS = M.WINOGRAD_MIN_PIXELS, 16      # every 3x3 ConvModule on the reproducible path
+    old, M.WINOGRAD_MIN_PIXELS = M.WINOGRAD_MIN_PIXELS, 16      # no MIOpen kernel with atomics for the 3x3 ConvModules on the small maps
     yield m
     M.WINOGRAD_MIN_PIXELS = old
 

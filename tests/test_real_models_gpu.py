@@ -76,7 +76,8 @@ def test_step_pins_loss_accuracy_gradient(ctx, case, fused):
             ref = g[key + "_grad"]
             big = ref.abs() > 1e-2 * float(g[key + "_gradmax"])
             # K1 only uses sign(grad): the sign must agree wherever the gradient is not at rounding level
-            B.check(f"{key}: gradient rel. L2 error", (got - ref).norm() / ref.norm(), 5e-3)
+            B.check(f"{key}: gradient rel. L2 error   (round 4, fp16x2 input gradient: measured <= 5.8e-4; round 3, bf16x2: 2.5e-3)",
+                    (got - ref).norm() / ref.norm(), 2e-3)
             B.check(f"{key}: sign mismatch where |g| > 1e-2 max", (torch.sign(got[big]) != torch.sign(ref[big])).float().mean(),
                     1e-3)
     B.report()
@@ -97,7 +98,7 @@ def test_five_step_largereps_matches_reference(ctx, case):
         B.check(f"{loss}: |acc - reference| (fraction)", (acc.cpu() - g[key + "_acc"]).abs().max(), 5e-3)
         got = xa.flatten()[g["idx"].cuda()].cpu()
         B.check(f"{loss}: fraction of x_adv samples != reference", ((got - g[key + "_x_adv_samples"]).abs() > 1e-6).float().mean(),
-                0.15)
+                0.12)   # round 4 (22-bit input gradient): measured 0 ... 5.2e-2 (round 3: <= 5.8e-2 against 0.15)
         # the argmax map the attack hands out IS the prediction of the returned iterate (no re-forward needed)
         with torch.no_grad():
             again = model(xa).max(1)[1]
@@ -142,6 +143,6 @@ def test_pirat_inner_pgd_convnext_s_fp32_and_bf16(ctx):
     with torch.no_grad():
         ce_b = torch.nn.functional.cross_entropy(model(xb), y).item()
     B.check("bf16: |CE gain / reference's gain - 1|", abs((ce_b - ce0) / (ce_ref - ce0) - 1), 0.05)
-    B.check("bf16: fraction of x_adv elements != reference (whole image)", (xb.cpu() != x_adv_ref).float().mean(), 0.5)
+    B.check("bf16: fraction of x_adv elements != reference (whole image)", (xb.cpu() != x_adv_ref).float().mean(), 0.2)   # measured 6.8e-2 (whole-model island; round 3: 0.35 -> 0.5)
     print("pgd CE clean / fp32 / bf16 / reference iterate:", ce0, ce, ce_b, ce_ref)
     B.report()

@@ -24,16 +24,14 @@ def timeit(fn, n=20):
 
 
 G, M, K, N = 36, 8192, 512, 512
-for dt in (torch.float16, torch.bfloat16):
+for dt in (torch.float16,):
     A2 = torch.randn(G, M, 2 * K, device="cuda").to(dt)      # [hi | mid]
     W2 = torch.randn(G, N, 2 * K, device="cuda").to(dt)      # [hi' | hi']
-    # (contiguous copies: a bmm on the K-strided VIEWS A2[:, :, :K] / W2[:, :, :K] faulted the GPU in this image --
-    # "Memory access fault by GPU node" inside the library kernel -- so the third product is timed on dense operands)
-    A1, W1 = A2[:, :, :K].contiguous(), W2[:, :, :K].contiguous()
     us = timeit(lambda: torch.bmm(A2, W2.transpose(1, 2)))
-    print(f"{dt} bmm 36x8192x1024x512 (16-bit out): {us:.0f} us = {2 * G * M * 2 * K * N / us / 1e6:.0f} TF/s", flush=True)
-    us1 = timeit(lambda: torch.bmm(A1, W1.transpose(1, 2)))
-    print(f"{dt} bmm 36x8192x512x512 (16-bit out): {us1:.0f} us = {2 * G * M * K * N / us1 / 1e6:.0f} TF/s;  sum {us + us1:.0f} us")
+    print(f"{dt} bmm 36x8192x1024x512 (16-bit out): {us:.0f} us = {2 * G * M * 2 * K * N / us / 1e6:.0f} TF/s  -> three products at this "
+          f"rate: {1.5 * us:.0f} us", flush=True)
+    # (the K = 512 product on its own -- 36 x 8192 x 512 x 512, dense fp16 operands or K-strided views alike -- faults the GPU in
+    # this image: "Memory access fault by GPU node" inside the library kernel; it is therefore not timed)
 # our kernel on the same product for reference
 from semseg import _native as Nn  # noqa: E402
 V = torch.randn(G, M, K, device="cuda")

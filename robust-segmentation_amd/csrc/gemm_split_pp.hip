@@ -1,0 +1,498 @@
+// M8, second pipeline ("ping-pong"): the same product as gemm_split_kernel -- same operand split, same packed weights, same
+// 128 x 128 x 32 tile, 2 x 2 waves of 64 x 64, same MFMA order per accumulator, hence the SAME BITS -- with the K loop
+// restructured around what round 4's counters showed (profiles/r4_gemm_split_pmc.txt: MFMA busy 37.6 %, 47 % of wave time
+// parked, time = one-product time + 98 us per extra product: staging and matrix work did not overlap):
+//
+//   * TWO LDS stages (2 x 2 TERMS x 8 KB) and ONE barrier per K step: while the MFMAs of step k read stage k & 1, the same
+//     wave splits and writes step k + 1 into the other stage.  64 KB (+ 1 KB row scales) per block: two blocks per CU.
+//   * the staging work is cut into micro-units (scale / pack, remainder, pack + ds_write, one weight piece, the loads) and
+//     placed BY HAND one per MFMA, pinned with sched_barrier: the VALU split runs in the shadow of the wave's own MFMAs
+//     (an MFMA holds the issue port 8 of its 32 cycles) instead of in a phase of its own behind a barrier.
+//   * two register sets (DEPTH = 2): a tile's global loads are issued two K steps before its split, behind the other
+//     set's (vmcnt is in-order, so the wait for one set leaves the younger one in flight).  256 VGPRs at two waves per SIMD
+//     pay for it; round 4's two-deep variant of the old loop lost its third block to the same registers.
+//   * the barrier sits BEFORE the last six MFMAs of the step, and the first fragments of the next step are read right
+//     behind it: the LDS latency after a barrier is covered by matrix work of the step before.
+//   * epilogue: wave-uniform row pointers (SGPR base + one 32-bit lane offset) instead of a 64-bit multiply per element.
+// TERMS 1 and 2 (bf16, bf16 x 2, fp16 x 2); three bf16 terms keep the old kernel (96 KB of stages: one block per CU).
+#include "gemm_split.h"
+
+namespace sea {
+
+template <int TERMS, bool F16, int KO = 0>
+__device__ __forceinline__ void mfma_one(f32x16& c, const bf16x8 (&a)[TERMS], const bf16x8 (&b)[TERMS], int j) {
+  // j-th product of the chain, smallest first: (mid, hi'), (hi, mid'), (hi, hi')
+  constexpr int NP = TERMS == 2 ? 3 : 1;
+  const int ia = (NP == 3 && j == 0) ? 1 : 0, ib = (NP == 3 && j == 1) ? 1 : 0;
+  if constexpr ((KO & 8) != 0) {   // no matrix instruction: the fragments stay live
+    asm volatile("" ::"v"(a[ia]), "v"(b[ib]));
+    return;
+  }
+  if constexpr (F16)
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[ia]), __builtin_bit_cast(f16x8, b[ib]), c, 0, 0, 0);
+  else
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ia], b[ib], c, 0, 0, 0);
+}
+
+// KO: knock-out mask of the timing-only builds of devtools/gemm_knockout.py (-DSEA_GEMM_KNOCKOUT); 0 in the product
+template <int TERMS, bool F16, bool EPI, int PRO, int DEPTH, int KO = 0>
+__global__ __launch_bounds__(256, 2) void gemm_split_pp_kernel(const GemmSplitArgs p) {
+  static_assert(TERMS == 1 || TERMS == 2, "ping-pong pipeline: one or two terms");
+  constexpr int NP = TERMS == 2 ? 3 : 1;               // MFMA products per (mi, ni, s)
+  constexpr int STAGE = 2 * TERMS * GS_IMG;            // A images, then W images, of one K step
+  constexpr bool HAS_T = (PRO == 1 || PRO == 3);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* const row_sc = (float*)(smem + 2 * STAGE);
+  float* const row_inv = row_sc + GS_BM;
+
+  const int M = p.M, N = p.N, K = p.K, Npad = p.Npad;
+  const int64_t lda = p.lda, ldc = p.ldc;
+  const int logical = (int)(blockIdx.x & 7) * p.per_xcd + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= p.per_xcd || logical >= p.total) return;
+  const int nb = logical % p.nblocks;
+  const int t2 = logical / p.nblocks;
+  const int mb = t2 % p.mblocks;
+  const int g = t2 / p.mblocks;
+  const int m0 = mb * GS_BM, n0 = nb * GS_BN;
+  const float* const w_inv = F16 ? (const float*)((const char*)p.w_inv + (int64_t)g * p.strideW) : nullptr;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int q = tid & 7, arow = tid >> 3;
+
+  const char* const Abase = (const char*)(p.A + (int64_t)g * p.strideA);
+  const char* const Tbase = HAS_T ? (const char*)(p.a_gelu_grad_of + (int64_t)g * p.strideA) : nullptr;
+  const float* const bias = p.bias;
+  const int relu = p.relu;
+  const float* const addg = (EPI && p.addend) ? p.addend + (int64_t)g * p.stride_add : nullptr;
+  const int64_t ld_add = p.ld_add;
+  float* const gelu_out = (EPI && p.gelu_out) ? p.gelu_out + (int64_t)g * p.strideC : nullptr;
+  const float* const gelu_src = (EPI && p.gelu_grad_of) ? p.gelu_grad_of + (int64_t)g * p.strideC : nullptr;
+
+  float a_sc[4] = {1.f, 1.f, 1.f, 1.f};
+  uint32_t aoff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int row = m0 + arow + 32 * i;
+    row = row < M ? row : M - 1;
+    aoff[i] = (uint32_t)(((int64_t)row * lda + 4 * q) * 4);
+  }
+  const char* const Wbase = p.W + (int64_t)g * p.strideW + (int64_t)n0 * 64;
+  const int64_t w_term = (int64_t)Npad * 64, w_kb = (int64_t)TERMS * w_term;
+  const uint32_t woff = (uint32_t)tid * 16;
+  const int nkb = K / GS_BK;
+
+  // LDS byte offsets of this lane (inside a stage): staging writes and fragment reads
+  uint32_t a_wr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = arow + 32 * i;
+    a_wr[i] = (uint32_t)(row * 64 + swz<false>(row, q >> 1) + (q & 1) * 8);
+  }
+  uint32_t w_wr[2 * TERMS];
+#pragma unroll
+  for (int i = 0; i < 2 * TERMS; ++i) {
+    const int pc = tid + 256 * i, term = pc >> 9, row = (pc & 511) >> 2, chunk = pc & 3;
+    w_wr[i] = (uint32_t)(TERMS * GS_IMG + term * GS_IMG + row * 64 + swz<false>(row, chunk));
+  }
+  const int ra = wm * 64 + r, rb = wn * 64 + r;
+  const uint32_t a_rd = (uint32_t)(ra * 64 + swz<false>(ra, h));                      // mi: + 2048, s: ^ 32, term: + GS_IMG
+  const uint32_t b_rd = (uint32_t)(TERMS * GS_IMG + rb * 64 + swz<false>(rb, h));
+
+  struct Tile {
+    f32x4 a[4];
+    f32x4 t[HAS_T ? 4 : 1];
+    u32x4 w[2 * TERMS];
+  };
+  Tile R0 = {}, R1 = {};   // (zeroed: a K loop shorter than the prefetch depth stages a set that was never loaded)
+
+  // Loads go through buffer descriptors: 32-bit lane offset + scalar K-step offset (no 64-bit VALU address arithmetic), and a
+  // tile past the end of K is fetched through a ZERO-RECORD descriptor: the range check drops the load, so the refills of
+  // the last DEPTH steps cost neither a branch in the K loop nor memory traffic (their registers are never multiplied).
+  const uint32_t a_bytes = (KO && (p.ko & 2)) ? 0u : (uint32_t)((((int64_t)(M - 1)) * lda + K) * 4);
+  const uint32_t w_bytes = (KO && (p.ko & 4)) ? 0u : (uint32_t)((int64_t)nkb * w_kb - (int64_t)n0 * 64);
+  auto fetch_a = [&](Tile& R, int kb) __attribute__((always_inline)) {
+    const int live = kb < nkb;
+    const int soff = kb * (GS_BK * 4);
+    const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void*)Abase, 0, live ? (int)a_bytes : 0, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) R.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra_, (int)aoff[i], soff, 0));
+    if constexpr (HAS_T) {
+      const __amdgpu_buffer_rsrc_t rt_ = __builtin_amdgcn_make_buffer_rsrc((void*)Tbase, 0, live ? (int)a_bytes : 0, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) R.t[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rt_, (int)aoff[i], soff, 0));
+    }
+  };
+  auto fetch_w = [&](Tile& R, int kb) __attribute__((always_inline)) {
+    const int live = kb < nkb;
+    const __amdgpu_buffer_rsrc_t rw_ = __builtin_amdgcn_make_buffer_rsrc((void*)Wbase, 0, live ? (int)w_bytes : 0, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 2 * TERMS; ++i)
+      R.w[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                             rw_, (int)woff, kb * (int)w_kb + (i >> 1) * (int)w_term + (i & 1) * 4096, 0));
+  };
+
+  // ---- staging micro-units of A row i: (0) prologue, scale, first term; (1) remainder; (2) second term + LDS writes
+  f32x4 sv;
+  uint32_t hi_a, hi_b;   // (two scalars, NOT a u32x2: hipcc 7.2 folds bit_cast<f16x2>(v[1]) of a 2-vector to v[0]'s halves)
+  auto unit_a = [&](Tile& R, int i, int part, char* stage) __attribute__((always_inline)) {
+    if (part == 0) {
+      f32x4 v = R.a[i];
+      if constexpr (PRO == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(R.t[i][e]);
+      }
+      if constexpr (PRO == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+      }
+      if constexpr (PRO == 3) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = R.t[i][e] > 0.f ? v[e] : 0.f;
+      }
+      if constexpr (F16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= a_sc[i];
+        hi_a = pack_f16(v[0], v[1]);
+        hi_b = pack_f16(v[2], v[3]);
+      } else {
+        hi_a = pack_bf16(v[0], v[1]);
+        hi_b = pack_bf16(v[2], v[3]);
+      }
+      sv = v;
+    } else if (part == 1) {
+      if constexpr (TERMS == 2) {
+        if constexpr (F16) {
+          const f32x2 f0 = __builtin_convertvector(__builtin_bit_cast(f16x2, hi_a), f32x2);
+          const f32x2 f1 = __builtin_convertvector(__builtin_bit_cast(f16x2, hi_b), f32x2);
+          sv[0] -= f0[0];
+          sv[1] -= f0[1];
+          sv[2] -= f1[0];
+          sv[3] -= f1[1];
+        } else {   // exact: the rounded-off part of an fp32 number is itself an fp32 number
+          // (no contraction with the multiply that ends a prologue: fma(t, 1 + erf, -hi) would take the remainder of the
+          // UNROUNDED product -- valid, but not the bits of the single-stage kernel)
+#pragma clang fp contract(off)
+          sv[0] -= __uint_as_float(hi_a << 16);
+          sv[1] -= __uint_as_float(hi_a & 0xffff0000u);
+          sv[2] -= __uint_as_float(hi_b << 16);
+          sv[3] -= __uint_as_float(hi_b & 0xffff0000u);
+        }
+      }
+    } else {
+      if constexpr ((KO & 16) != 0) {
+        asm volatile("" ::"v"(hi_a), "v"(hi_b), "v"(sv));
+        return;
+      }
+      *(u32x2*)(stage + a_wr[i]) = u32x2{hi_a, hi_b};
+      if constexpr (TERMS == 2) {
+        const u32x2 mid = F16 ? u32x2{pack_f16(sv[0], sv[1]), pack_f16(sv[2], sv[3])}
+                              : u32x2{pack_bf16(sv[0], sv[1]), pack_bf16(sv[2], sv[3])};
+        *(u32x2*)(stage + GS_IMG + a_wr[i]) = mid;
+      }
+    }
+  };
+  auto unit_w = [&](Tile& R, int i, char* stage) __attribute__((always_inline)) {
+    if constexpr ((KO & 16) != 0)
+      asm volatile("" ::"v"(R.w[i]));
+    else
+      *(u32x4*)(stage + w_wr[i]) = R.w[i];
+  };
+
+  bf16x8 Xa[2][TERMS], Xb[2][TERMS], Ya[2][TERMS], Yb[2][TERMS];
+  auto read_frags = [&](const char* stage, int s, bf16x8 (&fa)[2][TERMS], bf16x8 (&fb)[2][TERMS]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int t = 0; t < TERMS; ++t) fa[mi][t] = *(const bf16x8*)(stage + ((a_rd ^ (uint32_t)(32 * s)) + mi * 2048 + t * GS_IMG));
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int t = 0; t < TERMS; ++t) fb[ni][t] = *(const bf16x8*)(stage + ((b_rd ^ (uint32_t)(32 * s)) + ni * 2048 + t * GS_IMG));
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+#define SEA_PIN() __builtin_amdgcn_sched_barrier(0)
+  // one K step: MFMAs on stage `cur`; beside them tile Rn is split into stage `nxt` and refilled with tile `kf`
+  auto step = [&](char* cur, char* nxt, Tile& Rn, int kf) __attribute__((always_inline)) {
+    read_frags(cur, 1, Ya, Yb);
+    SEA_PIN();
+    // s = 0: four chains of NP products, one staging micro-unit behind each product (12 units at NP = 3)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        mfma_one<TERMS, F16, KO>(acc[c >> 1][c & 1], Xa[c >> 1], Xb[c & 1], j);
+        if constexpr (NP == 3) {
+          unit_a(Rn, c, j, nxt);
+        } else {
+          unit_a(Rn, c, 0, nxt);
+          unit_a(Rn, c, 2, nxt);
+        }
+        SEA_PIN();
+      }
+    }
+    // s = 1, first two chains: the weight pieces, then the refill loads
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        mfma_one<TERMS, F16, KO>(acc[0][c], Ya[0], Yb[c], j);
+        const int u = c * NP + j;            // 0 .. 2 NP - 1
+        if constexpr (NP == 3) {
+          if (u < 2 * TERMS) unit_w(Rn, u < 2 * TERMS ? u : 0, nxt);
+          if (u == 4) fetch_a(Rn, kf);
+          if (u == 5) fetch_w(Rn, kf);
+        } else {
+          unit_w(Rn, u, nxt);                // TERMS = 1: two pieces, two products
+          if (u == 0) fetch_a(Rn, kf);
+          if (u == 1) fetch_w(Rn, kf);
+        }
+        SEA_PIN();
+      }
+    }
+    __syncthreads();                         // every wave has read `cur` (its fragments are in registers) and written `nxt`
+    read_frags(nxt, 0, Xa, Xb);
+    SEA_PIN();
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        mfma_one<TERMS, F16, KO>(acc[1][c], Ya[1], Yb[c], j);
+        SEA_PIN();
+      }
+    }
+  };
+
+  char* const st0 = smem;
+  char* const st1 = smem + STAGE;
+  Tile& RA = R0;
+  Tile& RB = DEPTH == 2 ? R1 : R0;
+  // ---- prologue: the first tiles' loads go out BEFORE anything that waits (the row-scale words and their barrier, the
+  // epilogue's per-column constants): a short-K product is a chain of memory round trips, not a K loop
+  fetch_a(R0, 0);
+  fetch_w(R0, 0);
+  if constexpr (DEPTH == 2) {
+    fetch_a(R1, 1);
+    fetch_w(R1, 1);
+  }
+  float bv_c[2], wi_c[2];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int col = n0 + wn * 64 + ni * 32 + r;
+    bv_c[ni] = (bias && col < N) ? bias[col] : 0.f;
+    wi_c[ni] = (F16 && col < N) ? w_inv[col] : 1.f;
+  }
+  if constexpr (F16) {
+    if (tid < GS_BM) {
+      int row = m0 + tid;
+      row = row < M ? row : M - 1;
+      float sc, inv;
+      uint32_t word = p.amax_bits[p.amax_rows > 0 ? row / p.amax_rows : 0];
+      const float mul = p.amax_mul_dev ? *p.amax_mul_dev : p.amax_mul;
+      if (mul != 1.f) word = __float_as_uint(__uint_as_float(word) * mul) & 0x7fffffffu;
+      pow2_scale(word, sc, inv);
+      row_sc[tid] = sc;
+      row_inv[tid] = inv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_sc[i] = row_sc[arow + 32 * i];
+  }
+  SEA_PIN();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    unit_a(R0, i, 0, st0);
+    unit_a(R0, i, 1, st0);
+    unit_a(R0, i, 2, st0);
+  }
+#pragma unroll
+  for (int i = 0; i < 2 * TERMS; ++i) unit_w(R0, i, st0);
+  fetch_a(R0, DEPTH);
+  fetch_w(R0, DEPTH);
+  __syncthreads();
+  read_frags(st0, 0, Xa, Xb);
+  int kb = 0;
+  for (; kb + 2 <= nkb; kb += 2) {           // (one exit: a break between the two steps doubles the accumulators)
+    step(st0, st1, RB, kb + 1 + DEPTH);
+    step(st1, st0, RA, kb + 2 + DEPTH);
+  }
+  if (kb < nkb) step(st0, st1, RB, nkb);     // odd tail: nothing left to stage or fetch
+#undef SEA_PIN
+
+  // ---- epilogue.  The accumulators hold lane = column, 16 registers = rows (reg & 3) + 8 (reg >> 2) + 4 h of a 32 x 32
+  // tile: stored as they stand that is 64 four-byte stores per lane, and the store tail of a tile then costs what its whole
+  // K loop costs (knock-out timings, profiles/r5_gemm_knockout.md: 655 -> 502 us without the C stores; stores and loads
+  // share the address path, so the tail also stalls the OTHER block's loads).  Instead each wave turns its 64 x 64 tile
+  // through its own 8 KB of the (now idle) stages, 32 rows at a time, and stores 16 bytes per lane: a wave-instruction
+  // writes four 256-byte row segments, 16 of them per lane instead of 64.  No block barrier: after the last in-loop
+  // barrier nobody needs the stages (the fragments in flight are in registers), and a wave only reads what it wrote.
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int row0_u = m0 + (wave_u >> 1) * 64;
+  float* const Cg = p.C + (int64_t)g * p.strideC;
+  char* const scr = smem + wave_u * 8192;
+  const int lr = lane >> 4, lc = lane & 15;                   // read side: row 4 k + lr, columns 4 lc .. 4 lc + 3
+  const int col4 = n0 + wn * 64 + 4 * lc;
+  const bool vec = (((ldc | p.strideC | N) & 3) == 0) && ((((uintptr_t)p.C) & 15) == 0) &&
+                   (!(EPI && addg) || ((((ld_add | p.stride_add) & 3) == 0) && ((((uintptr_t)p.addend) & 15) == 0))) &&
+                   (!(EPI && gelu_out) || ((((uintptr_t)p.gelu_out) & 15) == 0)) &&
+                   (!(EPI && gelu_src) || ((((uintptr_t)p.gelu_grad_of) & 15) == 0));
+  const int off_c = lr * (int)ldc + col4;                     // (ldc < 2^28: checked by the launcher)
+  const int off_a = (EPI && addg) ? lr * (int)ld_add + col4 : 0;
+  uint32_t omax = 0;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    if (mi) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the reads of the first half are done)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int col = n0 + wn * 64 + ni * 32 + r;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row_l = (e & 3) + 8 * (e >> 2) + 4 * h;
+        // (exact: both scales are powers of two)
+        const float v = (F16 ? acc[mi][ni][e] * (row_inv[(wave_u >> 1) * 64 + mi * 32 + row_l] * wi_c[ni]) : acc[mi][ni][e]) + bv_c[ni];
+        *(float*)(scr + row_l * 256 + (ni * 32 + r) * 4) = v;
+      }
+      (void)col;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int row_u = row0_u + mi * 32 + 4 * k;
+      f32x4 v = *(const f32x4*)(scr + k * 1024 + lr * 256 + lc * 16);
+      if (row_u + lr >= M || col4 >= N) continue;
+      float* const crow = Cg + (int64_t)row_u * ldc;
+      if (vec) {
+        if (EPI && addg) v += *(const f32x4*)((addg + (int64_t)row_u * ld_add) + off_a);
+        if (relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        if (EPI && gelu_src) {
+          const f32x4 t = *(const f32x4*)((gelu_src + (int64_t)row_u * ldc) + off_c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(t[e]);
+        }
+        if constexpr ((KO & 64) != 0)
+          __builtin_nontemporal_store(v, (f32x4*)(crow + off_c));
+        else if ((KO & 1) == 0 || __float_as_uint(v[0]) == 0x7fc12345u)
+          *(f32x4*)(crow + off_c) = v;
+        if (EPI && gelu_out) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = gelu_f(v[e]);
+          *(f32x4*)((gelu_out + (int64_t)row_u * ldc) + off_c) = o;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t vb = __float_as_uint(v[e]) & 0x7fffffffu;
+          omax = vb > omax ? vb : omax;
+        }
+      } else {   // unaligned or ragged output: element by element
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (col4 + e < N) {
+            float x = v[e];
+            if (EPI && addg) x += (addg + (int64_t)row_u * ld_add)[off_a + e];
+            if (relu) x = x > 0.f ? x : 0.f;
+            if (EPI && gelu_src) x *= gelu_grad_f((gelu_src + (int64_t)row_u * ldc)[off_c + e]);
+            crow[off_c + e] = x;
+            if (EPI && gelu_out) (gelu_out + (int64_t)row_u * ldc)[off_c + e] = gelu_f(x);
+            const uint32_t vb = __float_as_uint(x) & 0x7fffffffu;
+            omax = vb > omax ? vb : omax;
+          }
+        }
+      }
+    }
+  }
+  if (p.out_amax != nullptr) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t other = (uint32_t)__shfl_xor((int)omax, o, 64);
+      omax = other > omax ? other : omax;
+    }
+    if (lane == 0 && omax > *(volatile uint32_t*)p.out_amax) atomicMax(p.out_amax, omax);
+  }
+}
+
+template <int TERMS, bool F16, bool EPI, int PRO, int DEPTH>
+static void pp_launch_one(const GemmSplitArgs& p, hipStream_t st) {
+  constexpr int lds = 2 * 2 * TERMS * GS_IMG + (F16 ? 2 * GS_BM * (int)sizeof(float) : 0);
+  auto k = gemm_split_pp_kernel<TERMS, F16, EPI, PRO, DEPTH>;
+  if (lds > 48 * 1024) {   // opt in once per device
+    static bool attr_set_dev[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_set_dev[dev & 63]) {
+      (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr_set_dev[dev & 63] = true;
+    }
+  }
+  hipLaunchKernelGGL(k, dim3(p.per_xcd * 8), dim3(256), (size_t)lds, st, p);
+}
+
+template <int TERMS, bool F16>
+static void pp_launch_mode(const GemmSplitArgs& p, int pro, bool fused, hipStream_t st) {
+  // the prologues with a second operand keep one register set (two would not fit 256 VGPRs next to 64 accumulators)
+  if (pro == 2) pp_launch_one<TERMS, F16, false, 2, 2>(p, st);
+  else if (pro == 1) pp_launch_one<TERMS, F16, false, 1, 1>(p, st);
+  else if (pro == 3) pp_launch_one<TERMS, F16, false, 3, 1>(p, st);
+  else if (fused) pp_launch_one<TERMS, F16, true, 0, 2>(p, st);
+  else pp_launch_one<TERMS, F16, false, 0, 2>(p, st);
+}
+
+#ifdef SEA_GEMM_KNOCKOUT
+template <int KO>
+static void ko_launch(const GemmSplitArgs& p, hipStream_t st) {
+  constexpr int lds = 2 * 2 * 2 * GS_IMG + 2 * GS_BM * (int)sizeof(float);
+  auto k = gemm_split_pp_kernel<2, true, false, 0, 2, KO>;
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL(k, dim3(p.per_xcd * 8), dim3(256), (size_t)lds, st, p);
+}
+// timing-only launches of the fp16 x 2 ping-pong kernel with parts knocked out: ko bits 1 no C stores, 2 no A loads, 4 no W
+// loads (zero-record descriptors), 8 no MFMAs, 16 no LDS staging writes.  Results are garbage by construction.
+extern "C" int sea_gemm_pp_knockout(const float* A, int64_t lda, const void* Wp, float* C, int64_t ldc, int M, int N, int K, int batch,
+                                    int64_t strideA, int64_t strideW_bytes, int64_t strideC, const uint32_t* amax_bits, int amax_rows,
+                                    int ko, void* stream) {
+  GemmSplitArgs p = {};
+  p.A = A; p.W = (const char*)Wp; p.C = C; p.lda = lda; p.ldc = ldc; p.strideA = strideA; p.strideW = strideW_bytes; p.strideC = strideC;
+  p.M = M; p.N = N; p.K = K; p.Npad = (N + GS_BN - 1) / GS_BN * GS_BN;
+  p.mblocks = (M + GS_BM - 1) / GS_BM; p.nblocks = p.Npad / GS_BN; p.total = p.mblocks * p.nblocks * batch; p.per_xcd = (p.total + 7) / 8;
+  p.amax_bits = amax_bits; p.amax_rows = amax_rows; p.amax_mul = 1.f;
+  p.w_inv = (const float*)((const char*)Wp + (int64_t)(K / GS_BK) * 2 * p.Npad * GS_BK * 2);
+  p.ko = ko;
+  const hipStream_t st = (hipStream_t)stream;
+  switch (ko & ~6) {   // bits 2 and 4 are run-time (descriptor sizes)
+    case 0: ko_launch<32>(p, st); break;     // (32: nothing compiled out, the run-time bits only)
+    case 1: ko_launch<1>(p, st); break;
+    case 8: ko_launch<8>(p, st); break;
+    case 9: ko_launch<9>(p, st); break;
+    case 16: ko_launch<16>(p, st); break;
+    case 24: ko_launch<24>(p, st); break;
+    case 25: ko_launch<25>(p, st); break;
+    case 64: ko_launch<64>(p, st); break;   // (64: non-temporal C stores)
+    case 72: ko_launch<72>(p, st); break;
+    default: return 1;
+  }
+  return (int)hipGetLastError();
+}
+#endif
+
+bool gemm_split_pp_launch(const GemmSplitArgs& p, int terms, int pro, bool fused, hipStream_t st) {
+  if (p.ldc >= (1ll << 28) || p.ld_add >= (1ll << 28)) return false;
+  if (terms == 22) pp_launch_mode<2, true>(p, pro, fused, st);
+  else if (terms == 2) pp_launch_mode<2, false>(p, pro, fused, st);
+  else if (terms == 1) pp_launch_mode<1, false>(p, pro, fused, st);
+  else return false;
+  return true;
+}
+
+}  // namespace sea

@@ -81,6 +81,7 @@ _SIGS = {
     "sea_gemm_split_pack": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp]),
     "sea_gemm_split": (_i, [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _vp]),
     "sea_gemm_split_mfma_shape": (_i, [_i]),
+    "sea_gemm_split_pipeline": (_i, [_i]),
     "sea_probe_stream_copy": (_i, [_vp, _vp, _sz, _i, _vp]),
     "sea_probe_stream_read": (_i, [_vp, _vp, _sz, _vp]),
 }

@@ -481,3 +481,54 @@ def test_prologue_with_addend_on_a_product_that_does_not_split(N, terms):
     got = N.gemm_split(A, Wp, a_gelu=True, addend=res, groups=4)
     want = N.gemm_split(A, Wp, a_gelu=True, groups=4) + res
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("M,K,Nn", [(1000, 192, 200), (300, 96, 130), (129, 32, 21), (2048, 512, 512), (517, 1024, 384)])
+def test_pingpong_pipeline_gives_the_bits_of_the_single_stage_loop(N, M, K, Nn):
+    """sea_gemm_split_pipeline(1) (two LDS stages, one barrier per K step, staging in the MFMA shadow: csrc/gemm_split_pp.hip)
+    against pipeline 0 (csrc/gemm_split.hip): same operand split, same MFMA order per accumulator -> bit-identical outputs
+    for every mode it serves (fp16 x 2, bf16 x 2, one bf16 term), every prologue, the fused epilogue, out_amax, batches,
+    odd / even / single K-step counts and ragged M, N"""
+    g = torch.Generator(device="cuda").manual_seed(M + K + Nn)
+    A = torch.randn(M, K, generator=g, device="cuda") * torch.exp2(torch.randint(-8, 3, (M, 1), generator=g, device="cuda").float())
+    W = torch.randn(Nn, K, generator=g, device="cuda") / K ** 0.5
+    bias = torch.randn(Nn, generator=g, device="cuda")
+    t = torch.randn(M, K, generator=g, device="cuda")
+    add = torch.randn(M, Nn, generator=g, device="cuda")
+    pre = torch.randn(M, Nn, generator=g, device="cuda")
+    A3 = torch.randn(3, M, K, generator=g, device="cuda")
+    W3 = torch.randn(3, Nn, K, generator=g, device="cuda") / K ** 0.5
+
+    def all_variants():
+        outs = {}
+        for terms in (22, 2, 1):
+            Wp = N.gemm_split_pack(W, terms=terms)
+            kw = dict(row_amax=True) if terms == 22 else {}
+            outs[terms, "plain"] = N.gemm_split(A, Wp, bias=bias, relu=True, **kw)
+            outs[terms, "gelu"] = N.gemm_split(A, Wp, a_gelu=True, **kw)
+            outs[terms, "addend"] = N.gemm_split(A, Wp, bias=bias, addend=add, **kw)
+            outs[terms, "gelu_grad"] = N.gemm_split(A, Wp, a_gelu_grad_of=t, **kw)
+            outs[terms, "gate"] = N.gemm_split(A, Wp, a_relu_gate=t, **kw)
+            go = torch.empty(M, Nn, device="cuda")
+            outs[terms, "gelu_out_pre"] = N.gemm_split(A, Wp, bias=bias, gelu_out=go, **kw)
+            outs[terms, "gelu_out"] = go
+            outs[terms, "gelu_grad_of"] = N.gemm_split(A, Wp, gelu_grad_of=pre, **kw)
+            outs[terms, "batch"] = N.gemm_split(A3, N.gemm_split_pack(W3, terms=terms), groups=1)
+        word = N.amax_word(A.device)
+        outs[22, "out_amax"] = N.gemm_split(A, N.gemm_split_pack(W, terms=22), out_amax=word).clone()
+        outs[22, "out_amax_word"] = word.clone()
+        return outs
+
+    L = N.lib()
+    assert L.sea_gemm_split_pipeline(-1) in (0, 1)
+    prev = L.sea_gemm_split_pipeline(0)
+    try:
+        o0 = all_variants()
+        assert L.sea_gemm_split_pipeline(1) == 0
+        o1 = all_variants()
+    finally:
+        L.sea_gemm_split_pipeline(prev)
+    for key, a in o0.items():
+        assert torch.equal(a, o1[key]), (key, (a.float() - o1[key].float()).abs().max().item())
+    ref = _ref(A, W, bias, True)
+    assert (o1[22, "plain"].double() - ref).abs().max().item() <= 3e-6 * ref.abs().max().item()

@@ -429,9 +429,10 @@ int sea_gemm_split(const float* A, int64_t lda, const void* Wp, float* C, int64_
 /* Tuning knob of the sea_gemm_split* kernels: MFMA fragment shape, 32 (v_mfma_f32_32x32x16_{f16,bf16}; default) or 16
  * (v_mfma_f32_16x16x32_*; also env SEA_GEMM_SHAPE=16).  Any other argument only queries.  Returns the previous shape. */
 int sea_gemm_split_mfma_shape(int shape);
-/* K-loop pipeline of the sea_gemm_split* kernels at one or two terms per operand (32x32x16 fragments): 1 = ping-pong (two LDS
- * stages, one barrier per K step, the operand split in the shadow of the wave's own MFMAs, two blocks per CU; default),
- * 0 = the single-stage loop (three blocks per CU; also env SEA_GEMM_PIPE=0).  Same split and same MFMA order: the two give the
+/* K-loop pipeline of the sea_gemm_split* kernels at one or two terms per operand (32x32x16 fragments): 0 = the single-stage
+ * loop (three blocks per CU), 1 = ping-pong (two LDS stages, one barrier per K step, the operand split in the shadow of the
+ * wave's own MFMAs, loads two K steps ahead, two blocks per CU), 2 = chosen per launch (default; also env SEA_GEMM_PIPE=0|1|2):
+ * ping-pong for launches with a prologue on A whose grid fills two blocks per CU.  Same split and same MFMA order: the kernels give the
  * same bits.  Any other argument only queries.  Returns the previous setting. */
 int sea_gemm_split_pipeline(int pipe);
 

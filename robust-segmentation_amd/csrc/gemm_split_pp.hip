@@ -328,99 +328,8 @@ __global__ __launch_bounds__(256, 2) void gemm_split_pp_kernel(const GemmSplitAr
   if (kb < nkb) step(st0, st1, RB, nkb);     // odd tail: nothing left to stage or fetch
 #undef SEA_PIN
 
-  // ---- epilogue.  The accumulators hold lane = column, 16 registers = rows (reg & 3) + 8 (reg >> 2) + 4 h of a 32 x 32
-  // tile: stored as they stand that is 64 four-byte stores per lane, and the store tail of a tile then costs what its whole
-  // K loop costs (knock-out timings, profiles/r5_gemm_knockout.md: 655 -> 502 us without the C stores; stores and loads
-  // share the address path, so the tail also stalls the OTHER block's loads).  Instead each wave turns its 64 x 64 tile
-  // through its own 8 KB of the (now idle) stages, 32 rows at a time, and stores 16 bytes per lane: a wave-instruction
-  // writes four 256-byte row segments, 16 of them per lane instead of 64.  No block barrier: after the last in-loop
-  // barrier nobody needs the stages (the fragments in flight are in registers), and a wave only reads what it wrote.
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const int row0_u = m0 + (wave_u >> 1) * 64;
-  float* const Cg = p.C + (int64_t)g * p.strideC;
-  char* const scr = smem + wave_u * 8192;
-  const int lr = lane >> 4, lc = lane & 15;                   // read side: row 4 k + lr, columns 4 lc .. 4 lc + 3
-  const int col4 = n0 + wn * 64 + 4 * lc;
-  const bool vec = (((ldc | p.strideC | N) & 3) == 0) && ((((uintptr_t)p.C) & 15) == 0) &&
-                   (!(EPI && addg) || ((((ld_add | p.stride_add) & 3) == 0) && ((((uintptr_t)p.addend) & 15) == 0))) &&
-                   (!(EPI && gelu_out) || ((((uintptr_t)p.gelu_out) & 15) == 0)) &&
-                   (!(EPI && gelu_src) || ((((uintptr_t)p.gelu_grad_of) & 15) == 0));
-  const int off_c = lr * (int)ldc + col4;                     // (ldc < 2^28: checked by the launcher)
-  const int off_a = (EPI && addg) ? lr * (int)ld_add + col4 : 0;
-  uint32_t omax = 0;
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    if (mi) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the reads of the first half are done)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int col = n0 + wn * 64 + ni * 32 + r;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row_l = (e & 3) + 8 * (e >> 2) + 4 * h;
-        // (exact: both scales are powers of two)
-        const float v = (F16 ? acc[mi][ni][e] * (row_inv[(wave_u >> 1) * 64 + mi * 32 + row_l] * wi_c[ni]) : acc[mi][ni][e]) + bv_c[ni];
-        *(float*)(scr + row_l * 256 + (ni * 32 + r) * 4) = v;
-      }
-      (void)col;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int row_u = row0_u + mi * 32 + 4 * k;
-      f32x4 v = *(const f32x4*)(scr + k * 1024 + lr * 256 + lc * 16);
-      if (row_u + lr >= M || col4 >= N) continue;
-      float* const crow = Cg + (int64_t)row_u * ldc;
-      if (vec) {
-        if (EPI && addg) v += *(const f32x4*)((addg + (int64_t)row_u * ld_add) + off_a);
-        if (relu) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-        }
-        if (EPI && gelu_src) {
-          const f32x4 t = *(const f32x4*)((gelu_src + (int64_t)row_u * ldc) + off_c);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(t[e]);
-        }
-        if constexpr ((KO & 64) != 0)
-          __builtin_nontemporal_store(v, (f32x4*)(crow + off_c));
-        else if ((KO & 1) == 0 || __float_as_uint(v[0]) == 0x7fc12345u)
-          *(f32x4*)(crow + off_c) = v;
-        if (EPI && gelu_out) {
-          f32x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = gelu_f(v[e]);
-          *(f32x4*)((gelu_out + (int64_t)row_u * ldc) + off_c) = o;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const uint32_t vb = __float_as_uint(v[e]) & 0x7fffffffu;
-          omax = vb > omax ? vb : omax;
-        }
-      } else {   // unaligned or ragged output: element by element
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (col4 + e < N) {
-            float x = v[e];
-            if (EPI && addg) x += (addg + (int64_t)row_u * ld_add)[off_a + e];
-            if (relu) x = x > 0.f ? x : 0.f;
-            if (EPI && gelu_src) x *= gelu_grad_f((gelu_src + (int64_t)row_u * ldc)[off_c + e]);
-            crow[off_c + e] = x;
-            if (EPI && gelu_out) (gelu_out + (int64_t)row_u * ldc)[off_c + e] = gelu_f(x);
-            const uint32_t vb = __float_as_uint(x) & 0x7fffffffu;
-            omax = vb > omax ? vb : omax;
-          }
-        }
-      }
-    }
-  }
-  if (p.out_amax != nullptr) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const uint32_t other = (uint32_t)__shfl_xor((int)omax, o, 64);
-      omax = other > omax ? other : omax;
-    }
-    if (lane == 0 && omax > *(volatile uint32_t*)p.out_amax) atomicMax(p.out_amax, omax);
-  }
+  // ---- epilogue (gemm_split.h): the tile goes through the idle stages and leaves as 16-byte stores
+  gemm_split_store_tile<F16, EPI, KO>(p, acc, g, m0, n0, smem, row_inv, bv_c, wi_c);
 }
 
 template <int TERMS, bool F16, bool EPI, int PRO, int DEPTH>

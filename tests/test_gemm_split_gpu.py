@@ -520,7 +520,7 @@ def test_pingpong_pipeline_gives_the_bits_of_the_single_stage_loop(N, M, K, Nn):
         return outs
 
     L = N.lib()
-    assert L.sea_gemm_split_pipeline(-1) in (0, 1)
+    assert L.sea_gemm_split_pipeline(-1) in (0, 1, 2)
     prev = L.sea_gemm_split_pipeline(0)
     try:
         o0 = all_variants()

@@ -190,6 +190,17 @@ int sea_apgd_track_graph(const float* loss_sum, const float* track_sum, const in
                          int n_iter, int early_stop, int32_t* acc_cnt, float* acc, float* loss_best,
                          float* loss_best_last, float* reduced_last, float* step, float* loss_steps, uint8_t* flags,
                          int32_t* done, const void* loss_workspace, void* stream);
+/* The same two with the run's radius (one float) and length (one int32) in device memory as well: nothing run-specific is
+ * left in the launch arguments, so ONE captured graph pair serves every stage, loss and batch of an evaluation (reference
+ * semseg/attacker.py:691-728: three apgd_train calls per attack with eps 2e / 1.5e / e and 0.3n / 0.3n / 0.4n iterations;
+ * tools/infer.py:338-370: three attacks per batch).  check_table and loss_steps must be sized for the longest run replayed. */
+int sea_apgd_linf_step_graph_dev(const float* x, float* x_adv, float* x_old, const float* grad, const float* step_b,
+                                 const float* eps_dev, const int32_t* iter_dev, int B, int64_t n_per_img, void* stream);
+int sea_apgd_track_graph_dev(const float* loss_sum, const float* track_sum, const int32_t* n_correct,
+                             const int32_t* n_ignored, int B, int64_t HW, int32_t* iter_dev, const int32_t* check_table,
+                             const int32_t* n_iter_dev, int early_stop, int32_t* acc_cnt, float* acc, float* loss_best,
+                             float* loss_best_last, float* reduced_last, float* step, float* loss_steps, uint8_t* flags,
+                             int32_t* done, const void* loss_workspace, void* stream);
 int sea_select_copy(const uint8_t* flags, float* x_adv, float* grad, float* x_best,
                     float* grad_best, float* x_best_adv, const void* pred, void* pred_best,
                     int pred_bytes, int B, int64_t n_per_img, int64_t HW, void* stream);

@@ -21,9 +21,12 @@ __global__ __launch_bounds__(1024) void apgd_track_kernel(
     int init, int32_t* __restrict__ acc_cnt, float* __restrict__ acc, float* __restrict__ loss_best,
     float* __restrict__ loss_best_last, float* __restrict__ reduced_last, float* __restrict__ step,
     float* __restrict__ loss_steps, uint8_t* __restrict__ flags, int32_t* __restrict__ done,
-    const LossRecord* __restrict__ records, int32_t* __restrict__ iter_dev, const int32_t* __restrict__ check_table) {
+    const LossRecord* __restrict__ records, int32_t* __restrict__ iter_dev, const int32_t* __restrict__ check_table,
+    const int32_t* __restrict__ n_iter_dev = nullptr) {
   // replayable form (HIP-graph mode): the loop index lives in *iter_dev, the checkpoint window of iteration i in
-  // check_table[i]; the counter is advanced at the very end, after every use (K1 of this step has read it already)
+  // check_table[i]; the counter is advanced at the very end, after every use (K1 of this step has read it already).
+  // With n_iter_dev the run length is device state too: one captured graph serves stages of any length.
+  if (n_iter_dev != nullptr) n_iter = *n_iter_dev;
   if (iter_dev != nullptr) {
     iter = *iter_dev;
     iter = iter < 0 ? 0 : (iter >= n_iter ? n_iter - 1 : iter);
@@ -254,12 +257,11 @@ extern "C" int sea_apgd_track(const float* loss_sum, const float* track_sum, con
   SEA_RETURN_LAST();
 }
 
-extern "C" int sea_apgd_track_graph(const float* loss_sum, const float* track_sum, const int32_t* n_correct,
-                                    const int32_t* n_ignored, int B, int64_t HW, int32_t* iter_dev,
-                                    const int32_t* check_table, int n_iter, int early_stop, int32_t* acc_cnt, float* acc,
-                                    float* loss_best, float* loss_best_last, float* reduced_last, float* step,
-                                    float* loss_steps, uint8_t* flags, int32_t* done, const void* loss_workspace,
-                                    void* stream) {
+static int track_graph_impl(const float* loss_sum, const float* track_sum, const int32_t* n_correct, const int32_t* n_ignored, int B,
+                            int64_t HW, int32_t* iter_dev, const int32_t* check_table, int n_iter, const int32_t* n_iter_dev,
+                            int early_stop, int32_t* acc_cnt, float* acc, float* loss_best, float* loss_best_last,
+                            float* reduced_last, float* step, float* loss_steps, uint8_t* flags, int32_t* done,
+                            const void* loss_workspace, void* stream) {
   SEA_CHECK_ARG(acc_cnt && acc && loss_best && loss_best_last && reduced_last && step && flags && done && B > 0 &&
                 HW > 0 && iter_dev && check_table && n_ignored && loss_steps && n_iter > 0);
   SEA_CHECK_ARG((track_sum && n_correct) || (loss_workspace && B <= 1024));
@@ -267,8 +269,33 @@ extern "C" int sea_apgd_track_graph(const float* loss_sum, const float* track_su
                      track_sum, n_correct, n_ignored, B, HW, 0, n_iter, 0, early_stop, 0, acc_cnt, acc, loss_best, loss_best_last, reduced_last,
                      step, loss_steps, flags, done,
                      (track_sum && n_correct) ? (const LossRecord*)nullptr : (const LossRecord*)loss_workspace, iter_dev,
-                     check_table);
+                     check_table, n_iter_dev);
   SEA_RETURN_LAST();
+}
+
+extern "C" int sea_apgd_track_graph(const float* loss_sum, const float* track_sum, const int32_t* n_correct,
+                                    const int32_t* n_ignored, int B, int64_t HW, int32_t* iter_dev,
+                                    const int32_t* check_table, int n_iter, int early_stop, int32_t* acc_cnt, float* acc,
+                                    float* loss_best, float* loss_best_last, float* reduced_last, float* step,
+                                    float* loss_steps, uint8_t* flags, int32_t* done, const void* loss_workspace,
+                                    void* stream) {
+  return track_graph_impl(loss_sum, track_sum, n_correct, n_ignored, B, HW, iter_dev, check_table, n_iter, nullptr, early_stop,
+                          acc_cnt, acc, loss_best, loss_best_last, reduced_last, step, loss_steps, flags, done, loss_workspace,
+                          stream);
+}
+
+// the same with the run length read from device memory (check_table and loss_steps sized for the longest run the caller
+// will replay): a captured graph then serves runs of any length
+extern "C" int sea_apgd_track_graph_dev(const float* loss_sum, const float* track_sum, const int32_t* n_correct,
+                                        const int32_t* n_ignored, int B, int64_t HW, int32_t* iter_dev,
+                                        const int32_t* check_table, const int32_t* n_iter_dev, int early_stop, int32_t* acc_cnt,
+                                        float* acc, float* loss_best, float* loss_best_last, float* reduced_last, float* step,
+                                        float* loss_steps, uint8_t* flags, int32_t* done, const void* loss_workspace,
+                                        void* stream) {
+  SEA_CHECK_ARG(n_iter_dev != nullptr);
+  return track_graph_impl(loss_sum, track_sum, n_correct, n_ignored, B, HW, iter_dev, check_table, 1, n_iter_dev, early_stop,
+                          acc_cnt, acc, loss_best, loss_best_last, reduced_last, step, loss_steps, flags, done, loss_workspace,
+                          stream);
 }
 
 extern "C" int sea_select_copy(const uint8_t* flags, float* x_adv, float* grad, float* x_best, float* grad_best,

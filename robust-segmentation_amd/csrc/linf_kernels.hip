@@ -85,10 +85,11 @@ __global__ __launch_bounds__(256) void apgd_linf_step_v1(const float* __restrict
 // x_adv <- new iterate, element by element (each element is read before it is written, by the same lane).
 __global__ __launch_bounds__(256) void apgd_linf_step_inplace_v4(const f4* __restrict__ x, f4* __restrict__ xadv,
                                                                  f4* __restrict__ xold, const f4* __restrict__ grad,
-                                                                 const float* __restrict__ step_b, float eps,
+                                                                 const float* __restrict__ step_b, float eps_val,
                                                                  const int32_t* __restrict__ iter_dev,
-                                                                 int64_t n4_per_img) {
+                                                                 int64_t n4_per_img, const float* __restrict__ eps_dev) {
   const int b = blockIdx.y;
+  const float eps = eps_dev ? *eps_dev : eps_val;   // (the radius as run-invariant device state: one captured graph serves every stage)
   const float st = step_b[b];
   const bool first = *iter_dev <= 0;
   const float a = first ? 1.0f : 0.75f;
@@ -105,9 +106,11 @@ __global__ __launch_bounds__(256) void apgd_linf_step_inplace_v4(const f4* __res
 // not 16-byte aligned): one float per lane and trip
 __global__ __launch_bounds__(256) void apgd_linf_step_inplace_v1(const float* __restrict__ x, float* __restrict__ xadv,
                                                                  float* __restrict__ xold, const float* __restrict__ grad,
-                                                                 const float* __restrict__ step_b, float eps,
-                                                                 const int32_t* __restrict__ iter_dev, int64_t n_per_img) {
+                                                                 const float* __restrict__ step_b, float eps_val,
+                                                                 const int32_t* __restrict__ iter_dev, int64_t n_per_img,
+                                                                 const float* __restrict__ eps_dev) {
   const int b = blockIdx.y;
+  const float eps = eps_dev ? *eps_dev : eps_val;
   const float st = step_b[b];
   const bool first = *iter_dev <= 0;
   const float a = first ? 1.0f : 0.75f;
@@ -254,9 +257,8 @@ extern "C" int sea_apgd_linf_step(const float* x, const float* x_adv, const floa
   SEA_RETURN_LAST();
 }
 
-extern "C" int sea_apgd_linf_step_graph(const float* x, float* x_adv, float* x_old, const float* grad,
-                                        const float* step_b, float eps, const int32_t* iter_dev, int B,
-                                        int64_t n_per_img, void* stream) {
+static int linf_step_graph_impl(const float* x, float* x_adv, float* x_old, const float* grad, const float* step_b, float eps,
+                                const float* eps_dev, const int32_t* iter_dev, int B, int64_t n_per_img, void* stream) {
   SEA_CHECK_ARG(x && x_adv && x_old && grad && step_b && iter_dev && B > 0 && n_per_img > 0 && B <= 65535);
   int cap = kMaxGridX / B;
   if (cap < 1) cap = 1;
@@ -264,15 +266,29 @@ extern "C" int sea_apgd_linf_step_graph(const float* x, float* x_adv, float* x_o
     int gx1 = grid_for(n_per_img, 256);
     if (gx1 > cap) gx1 = cap;
     hipLaunchKernelGGL(apgd_linf_step_inplace_v1, dim3(gx1, B), dim3(256), 0, (hipStream_t)stream, x, x_adv, x_old, grad, step_b,
-                       eps, iter_dev, n_per_img);
+                       eps, iter_dev, n_per_img, eps_dev);
     SEA_RETURN_LAST();
   }
   const int64_t n4 = n_per_img / 4;
   int gx = grid_for(n4, 256);
   if (gx > cap) gx = cap;
   hipLaunchKernelGGL(apgd_linf_step_inplace_v4, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, (const f4*)x, (f4*)x_adv,
-                     (f4*)x_old, (const f4*)grad, step_b, eps, iter_dev, n4);
+                     (f4*)x_old, (const f4*)grad, step_b, eps, iter_dev, n4, eps_dev);
   SEA_RETURN_LAST();
+}
+
+extern "C" int sea_apgd_linf_step_graph(const float* x, float* x_adv, float* x_old, const float* grad,
+                                        const float* step_b, float eps, const int32_t* iter_dev, int B,
+                                        int64_t n_per_img, void* stream) {
+  return linf_step_graph_impl(x, x_adv, x_old, grad, step_b, eps, nullptr, iter_dev, B, n_per_img, stream);
+}
+
+// the same with the radius read from device memory (one float): a captured graph then serves runs of any radius
+extern "C" int sea_apgd_linf_step_graph_dev(const float* x, float* x_adv, float* x_old, const float* grad,
+                                            const float* step_b, const float* eps_dev, const int32_t* iter_dev, int B,
+                                            int64_t n_per_img, void* stream) {
+  SEA_CHECK_ARG(eps_dev != nullptr);
+  return linf_step_graph_impl(x, x_adv, x_old, grad, step_b, 0.f, eps_dev, iter_dev, B, n_per_img, stream);
 }
 
 template <int OP>

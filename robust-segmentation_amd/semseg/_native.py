@@ -45,6 +45,9 @@ _SIGS = {
     "sea_apgd_linf_step_graph": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i64, _vp]),
     "sea_apgd_track_graph": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _vp, _vp]),
+    "sea_apgd_linf_step_graph_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp]),
+    "sea_apgd_track_graph_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                      _vp, _vp, _vp]),
     "sea_select_copy": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _vp]),
     "sea_count_ignored": (_i, [_vp, _i, _i, _i64, _vp, _vp]),
     "sea_worst_miou_greedy": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
@@ -327,18 +330,35 @@ def apgd_track(stats, n_ignored, HW: int, it: int, n_iter: int, check_k: int, ea
                                 _p(stats.get("workspace")), _stream()), "sea_apgd_track")
 
 
-def apgd_linf_step_graph(x, x_adv, x_old, grad, step_b, eps: float, iter_dev):
-    """K1 in place with the loop index read from device memory (HIP-graph mode): x_old <- x_adv, x_adv <- new."""
+def apgd_linf_step_graph(x, x_adv, x_old, grad, step_b, eps, iter_dev):
+    """K1 in place with the loop index read from device memory (HIP-graph mode): x_old <- x_adv, x_adv <- new.
+    ``eps``: a Python float, or ONE float32 in device memory (the radius as device state too)."""
     _dev(x, x_adv, x_old, grad, step_b, iter_dev)
     for t in (x, x_adv, x_old, grad):
         if t.dtype != torch.float32 or not t.is_contiguous():
             raise SeaNativeError("apgd_linf_step_graph: contiguous float32 buffers expected")
+    if torch.is_tensor(eps):
+        if eps.dtype != torch.float32 or eps.numel() != 1 or eps.device != x.device:
+            raise SeaNativeError("apgd_linf_step_graph: a tensor eps must be one float32 on x's device")
+        _check(lib().sea_apgd_linf_step_graph_dev(_p(x), _p(x_adv), _p(x_old), _p(grad), _p(_f32c(step_b)), _p(eps), _p(iter_dev),
+                                                  x.shape[0], x[0].numel(), _stream()), "sea_apgd_linf_step_graph_dev")
+        return
     _check(lib().sea_apgd_linf_step_graph(_p(x), _p(x_adv), _p(x_old), _p(grad), _p(_f32c(step_b)), eps, _p(iter_dev),
                                           x.shape[0], x[0].numel(), _stream()), "sea_apgd_linf_step_graph")
 
 
-def apgd_track_graph(stats, n_ignored, HW: int, iter_dev, check_table, n_iter: int, early_stop: bool, st):
-    """K7 with the loop index and the checkpoint schedule in device memory; advances ``iter_dev``."""
+def apgd_track_graph(stats, n_ignored, HW: int, iter_dev, check_table, n_iter, early_stop: bool, st):
+    """K7 with the loop index and the checkpoint schedule in device memory; advances ``iter_dev``.  ``n_iter``: an int, or ONE
+    int32 in device memory (``check_table`` and ``st.loss_steps`` then sized for the longest run replayed)."""
+    if torch.is_tensor(n_iter):
+        if n_iter.dtype != torch.int32 or n_iter.numel() != 1:
+            raise SeaNativeError("apgd_track_graph: a tensor n_iter must be one int32")
+        _check(lib().sea_apgd_track_graph_dev(_p(stats["loss_sum"]), _p(stats["track_sum"]), _p(stats["n_correct"]),
+                                              _p(n_ignored), st.B, HW, _p(iter_dev), _p(check_table), _p(n_iter), int(early_stop),
+                                              _p(st.acc_cnt), _p(st.acc), _p(st.loss_best), _p(st.loss_best_last),
+                                              _p(st.reduced_last), _p(st.step), _p(st.loss_steps), _p(st.flags), _p(st.done),
+                                              _p(stats.get("workspace")), _stream()), "sea_apgd_track_graph_dev")
+        return
     _check(lib().sea_apgd_track_graph(_p(stats["loss_sum"]), _p(stats["track_sum"]), _p(stats["n_correct"]),
                                       _p(n_ignored), st.B, HW, _p(iter_dev), _p(check_table), n_iter, int(early_stop),
                                       _p(st.acc_cnt), _p(st.acc), _p(st.loss_best), _p(st.loss_best_last),
@@ -809,7 +829,9 @@ class _GemmEpilogue(C.Structure):       # SeaGemmEpilogue of include/sea_hip.h
 def _amax_words(A3, M, K, G, sA, groups, per_row=False):
     """exact per-group maxima of |A| (float bits), one word per M / groups rows -- or one per ROW (``per_row``: gradient
     operands, whose rows span many orders of magnitude)"""
-    if per_row and G == 1:
+    if per_row and G != 1:
+        raise SeaNativeError("gemm_split: row_amax (one scale word per row) is defined for a single matrix, not a batch of them")
+    if per_row:
         words = torch.empty(M, dtype=torch.int32, device=A3.device)
         _check(lib().sea_absmax_bits(_p(A3), A3.stride(1), M, K, 1, 0, 1, _p(words), _stream()), "sea_absmax_bits")
         return words, 1
@@ -834,7 +856,10 @@ def gemm_split(A, Wp: PackedWeight, bias=None, relu: bool = False, out=None, ama
     ``gelu_out`` (layout of out) receives GELU(out) while out keeps the pre-activation; the result is multiplied by
     GELU'(``gelu_grad_of``) (layout of out).  Prologue instead (exclusive): A is read as A * GELU'(``a_gelu_grad_of``)
     (same shape and strides as A; terms 2 or 22), as (``a_relu_gate`` > 0 ? A : 0) (same layout), or as GELU(A)
-    (``a_gelu``)."""
+    (``a_gelu``).
+    Split-K products (chosen here for small tile grids) go through ONE partial-product workspace per device: a caller that
+    runs these GEMMs on several streams at once must order them itself, and a caller that captures them into a HIP graph
+    must hold ``ksplit_workspace_pin(device)`` for as long as the graph may replay (``ApgdRun`` does both)."""
     gate = a_relu_gate is not None
     if gate:
         if a_gelu_grad_of is not None:
@@ -895,7 +920,14 @@ def gemm_split(A, Wp: PackedWeight, bias=None, relu: bool = False, out=None, ama
                          a_relu_gate=a_gelu_grad_of if gate else None, row_amax=row_amax,
                          amax_mul=mul_dev if mul_dev is not None else amax_mul)
         out += addend
-        return torch.relu_(out) if relu else out
+        if relu:
+            torch.relu_(out)
+        if out_amax is not None and Wp.terms == 22:
+            # the contract "out_amax receives the bits of max|out|" holds on this path too (a consumer GEMM that read a
+            # zero word would scale by 2^126)
+            O2 = out if out.dim() == 3 else out.unsqueeze(0)
+            _check(lib().sea_absmax_bits(_p(O2), O2.stride(1), M, Wp.N, G, sC, 0, _p(out_amax), _stream()), "sea_absmax_bits")
+        return out
     if fused:
         epi = _GemmEpilogue()
         if addend is not None:

@@ -1255,8 +1255,7 @@ class UperNetForSemanticSegmentation(nn.Module):
         """bf16 autocast + frozen weights + eval mode = the attack's forward (PIR-AT inner PGD, BASELINE configs[3])"""
         return (AUTOCAST_ISLAND == "model" and lbl is None and not self.training and torch.is_autocast_enabled() and input.is_cuda
                 and input.dtype == torch.float32 and GEMM_TERMS != 0
-                and not self.decode_head.classifier.weight.requires_grad
-                and not self.backbone.downsample_layers[1][1].weight.requires_grad)
+                and not any(p.requires_grad for p in self.parameters()))       # EVERY weight frozen, not a sample of them
 
     def forward(self, input, lbl=None):
         if self._attack_island(input, lbl):

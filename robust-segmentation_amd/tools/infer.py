@@ -353,6 +353,8 @@ def _main(argv=None):
                 logs[loss_][rows] = _masked_long(pred, y).to(lbl_dtype).cpu()
     torch.cuda.synchronize()
     t_attack = time.time() - t_attack
+    # the evaluation's ONE captured graph pair (every stage, loss and batch replayed it) and its activation pool
+    attacker.release_graph_cache(model)
 
     # ---- the ONE collective, then host-side worst-case bookkeeping on rank 0 ----------------------------
     stats.all_reduce()

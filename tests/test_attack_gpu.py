@@ -302,3 +302,60 @@ def test_hip_graph_mode_on_images_whose_size_is_not_a_multiple_of_four(capfd):
     assert "continuing with the eager loop" not in capfd.readouterr().err
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
+
+
+def test_one_captured_graph_pair_serves_every_stage_loss_and_batch(A):
+    """Round 5: the radius, the run length and the checkpoint table are device state (sea_apgd_linf_step_graph_dev /
+    sea_apgd_track_graph_dev) and the buffers a captured graph addresses live in a slot of the model: ONE capture serves the
+    nine apgd_train calls of a SEA batch (three losses x three stages of different radius and length, reference
+    attacker.py:691-728, tools/infer.py:338-370) and the next batch of the same shape -- with the bits of a capture per run."""
+    from oracle.tiny_models import make_labels
+    net = PointwiseNet(21, seed=11)
+    g = torch.Generator().manual_seed(23)
+    xs = [torch.rand(3, 3, 16, 20, generator=g) for _ in range(2)]
+    ys = [make_labels(net, x, ignore_frac=0.04, flip_frac=0.1, seed=3 + i).cuda() for i, x in enumerate(xs)]
+    net = net.cuda()
+    xs = [x.cuda() for x in xs]
+    w = torch.rand(21, generator=g).cuda()
+    noises = [[torch.rand(3, 3, 16, 20, generator=g).cuda() for _ in range(3)] for _ in range(6)]
+
+    captures = []
+    real = A.ApgdRun._capture
+
+    def counting(self, i):
+        captures.append((self.n_iter, self.eps))
+        return real(self, i)
+
+    def evaluate():
+        outs, k = [], 0
+        for x, y in zip(xs, ys):
+            for loss in ("mask-ce-bal", "mask-ce-avg", "js-avg"):
+                outs.append(A.apgd_largereps(net, x, y, w, eps=4.0 / 255, n_iter=60, loss=loss, use_rs=True, early_stop=True,
+                                             track_loss="ce-avg", num_classes=21, noises=noises[k], return_pred=True))
+                k += 1
+        return outs
+
+    A.ApgdRun._capture = counting
+    old = A.GRAPH_CACHE
+    try:
+        A.release_graph_cache()
+        A.GRAPH_CACHE = False
+        per_run = evaluate()
+        n_per_run = len(captures)
+        captures.clear()
+        A.GRAPH_CACHE = True
+        cached = evaluate()
+        n_cached = len(captures)
+        again = evaluate()                       # the slot (and its pair) survive the evaluation
+    finally:
+        A.ApgdRun._capture, A.GRAPH_CACHE = real, old
+    assert n_per_run == 18 and n_cached == 1 and len(captures) == 1, (n_per_run, n_cached, len(captures))
+    for a, b, c in zip(per_run, cached, again):
+        for t, u, v in zip(a, b, c):
+            if t is None:
+                continue
+            assert torch.equal(t, u) and torch.equal(t, v)
+    # results are copies: a later run does not overwrite what an earlier one handed out
+    assert not torch.equal(cached[0][0], cached[1][0])
+    A.release_graph_cache(net)
+    assert net not in A._GRAPH_SLOTS

@@ -50,7 +50,7 @@ def test_accuracy_matches_fp32_gemm(N, M, K, Nn):
     e2 = (N.gemm_split(A, N.gemm_split_pack(W, terms=2)).double() - ref).abs().max().item() / scale
     e22 = (N.gemm_split(A, N.gemm_split_pack(W, terms=22)).double() - ref).abs().max().item() / scale
     print(f"M={M} K={K} N={Nn}: max err / max|C|  hipBLASLt fp32 {e_lib:.2e}   bf16x3 {e3:.2e}   fp16x2 {e22:.2e}   bf16x2 {e2:.2e}")
-    assert e22 <= max(6.0 * e_lib, 2e-6), (e22, e_lib)        # 22 significant bits per operand
+    assert e22 <= max(2.0 * e_lib, 2e-6), (e22, e_lib)        # 22 significant bits per operand: measured 0.3-1.5 x the fp32 GEMM's own error
     assert e3 <= max(4.0 * e_lib, 1e-6) and e3 <= 3e-6, (e3, e_lib)   # fp32-level (measured: 0.8-2.4x hipBLASLt's fp32 error)
     assert e2 <= 2e-5, e2                                      # 16 significant bits per operand
 

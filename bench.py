@@ -397,6 +397,10 @@ def main():
                          + "bounds / Winograd tile maxima; gradient: exact row maxima / Winograd tile maxima / row bounds carried "
                          + "through the MLP), split-K for small tile grids, GELU / GELU' / ReLU-gate prologues")
                 if GEMM_TERMS in (2, 3, 22) else "hipBLASLt fp32",
+                **({"attention": {"forward_terms": N.attn_terms_fwd(), "input_gradient_terms": N.attn_terms_bwd(),
+                                  "note": "M7b flash attention on the 16-bit matrix cores: 3 = three bf16 terms per operand (fp32 "
+                                          "operands exactly), 22 = fp16 x 2 (22 significant bits), 2 = two bf16 terms, 0 = fp32 MFMA"}}
+                   if args.backbone.startswith("vit_") else {}),
                 **({"per_rank": per_rank} if per_rank else {}),
             },
             "roofline": roof,

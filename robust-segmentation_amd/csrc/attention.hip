@@ -361,6 +361,10 @@ int sea_attention_bwd_bf16(const float* q, const float* k, const float* v, int64
                            float scale, const float* grad_out, const float* lse, const float* delta, float* dq, float* dk,
                            float* dv, int64_t gsb, int64_t gsh, int64_t gst, int terms, hipStream_t stream);
 
+int sea_attention_bwd_f16x2(const float* q, const float* k, const float* v, int64_t sb, int64_t sh, int64_t st, int B, int H, int T,
+                            float scale, const float* grad_out, const float* lse, const float* delta, uint32_t* amax_ws, float* dq,
+                            float* dk, float* dv, int64_t gsb, int64_t gsh, int64_t gst, hipStream_t stream);
+
 // SEA_ATTN_TERMS (forward) / SEA_ATTN_TERMS_BWD: 3 or 2 = bf16 terms per operand on v_mfma_f32_32x32x16_bf16, 0 = the fp32
 // MFMA kernels of this file.  Defaults: 3 (= the fp32 operands exactly) forward AND backward (round 4: the evaluation is
 // fp32-equivalent end to end; 2 backward was round 3's default: the attack consumes only the sign of the input gradient).
@@ -387,7 +391,7 @@ extern "C" int sea_attention_fwd(const float* q, const float* k, const float* v,
 static int attention_bwd_impl(const float* q, const float* k, const float* v, int64_t sb, int64_t sh, int64_t st, int B, int H,
                               int T, int D, float scale, const float* out, const float* grad_out, const float* lse,
                               float* delta, float* dq, float* dk, float* dv, int64_t gsb, int64_t gsh, int64_t gst,
-                              int bwd_terms, void* stream);
+                              int bwd_terms, void* stream, uint32_t* amax_ws = nullptr);
 
 extern "C" int sea_attention_bwd(const float* q, const float* k, const float* v, int64_t sb, int64_t sh, int64_t st, int B, int H,
                                  int T, int D, float scale, const float* out, const float* grad_out, const float* lse,
@@ -408,10 +412,21 @@ extern "C" int sea_attention_bwd_terms(const float* q, const float* k, const flo
                             stream);
 }
 
+// fp16 x 2 backward (22 significant bits per operand in three MFMA products per pair, csrc/attention_bf16.hip): the accuracy of
+// the three-term bf16 mode at the cost of the two-term one.  amax_ws: 4 B H device words of scratch.
+extern "C" int sea_attention_bwd_f16(const float* q, const float* k, const float* v, int64_t sb, int64_t sh, int64_t st, int B, int H,
+                                     int T, int D, float scale, const float* out, const float* grad_out, const float* lse,
+                                     float* delta, uint32_t* amax_ws, float* dq, float* dk, float* dv, int64_t gsb, int64_t gsh,
+                                     int64_t gst, void* stream) {
+  SEA_CHECK_ARG(amax_ws != nullptr);
+  return attention_bwd_impl(q, k, v, sb, sh, st, B, H, T, D, scale, out, grad_out, lse, delta, dq, dk, dv, gsb, gsh, gst, 22,
+                            stream, amax_ws);
+}
+
 static int attention_bwd_impl(const float* q, const float* k, const float* v, int64_t sb, int64_t sh, int64_t st, int B, int H,
                               int T, int D, float scale, const float* out, const float* grad_out, const float* lse,
                               float* delta, float* dq, float* dk, float* dv, int64_t gsb, int64_t gsh, int64_t gst,
-                              int bwd_terms, void* stream) {
+                              int bwd_terms, void* stream, uint32_t* amax_ws) {
   SEA_CHECK_ARG(q && k && v && out && grad_out && lse && delta && dq && dk && dv && B > 0 && H > 0 && T > 0 && D == kD);
   SEA_CHECK_ARG((sb % 4) == 0 && (sh % 4) == 0 && (st % 4) == 0 && (gsb % 4) == 0 && (gsh % 4) == 0 && (gst % 4) == 0);
   SEA_CHECK_ARG(((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)out) | ((uintptr_t)grad_out) |
@@ -420,6 +435,8 @@ static int attention_bwd_impl(const float* q, const float* k, const float* v, in
   hipStream_t s = (hipStream_t)stream;
   const int64_t rows = (int64_t)B * T * H;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, out, grad_out, T, H, rows, delta);
+  if (bwd_terms == 22)
+    return sea_attention_bwd_f16x2(q, k, v, sb, sh, st, B, H, T, scale, grad_out, lse, delta, amax_ws, dq, dk, dv, gsb, gsh, gst, s);
   if (const int terms = bwd_terms)
     return sea_attention_bwd_bf16(q, k, v, sb, sh, st, B, H, T, scale, grad_out, lse, delta, dq, dk, dv, gsb, gsh, gst, terms, s);
   dim3 grid((T + 127) / 128, H, B), block(256);

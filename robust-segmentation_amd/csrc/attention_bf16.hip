@@ -410,6 +410,335 @@ __global__ __launch_bounds__(256, TERMS == 2 ? 2 : 1) void attn_dkv_bf16_kernel(
   store_rows_t(dv + (int64_t)b * gsb + (int64_t)h * gsh, gst, k_row, k_ok, lane, dv0, dv1, 1.f);
 }
 
+
+// =====================================================================================================================
+// fp16 x 2 backward (round 5): 22 significant bits per operand in THREE products per pair, where three bf16 terms need six.
+// hi = fp16(a s), mid = fp16(a s - hi) with a power-of-two scale s per operand GROUP that puts the group's largest magnitude
+// below 2^14 (csrc/gemm_split.hip); fp16's 5 exponent bits then leave 17 binades under that maximum at full 22-bit
+// precision and an absolute floor of 2^-38 of it below -- wide enough for scales that are BOUNDS rather than exact maxima:
+//   * row fragments (the lane's own Q / K / V / dO row, the B operand of the first products): the row's exact maximum,
+//     computed in the lane; the accumulator is multiplied back by the exact inverse;
+//   * staged 64 x 64 tiles (K, V in dQ; Q, dO in dK / dV): ONE scale per (image, head) from a 48-block pre-pass over the
+//     four tensors (attn_amax_bh_kernel): a tile's rows are the CONTRACTION index of the transposed products, so their scale
+//     must be uniform over everything an accumulator sums -- all tiles of the (image, head);
+//   * the accumulator operands of the transposed products: P <= 1 takes 2^14; dS = P (dP - delta) scale takes the bound
+//     2 x 64 max|dO| max|V| scale (|dP| and |delta| are both 64-term dot products of dO with V rows resp. their convex
+//     combination), per query row in dQ (the lane's own max|dO_i|), per (image, head) in dK / dV.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pack_f16(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+}
+// power-of-two scale for a group whose largest |value| has the float bits `amax_bits`: amax * scale in [2^13, 2^14)
+__device__ __forceinline__ void attn_pow2_scale(uint32_t amax_bits, float& scale, float& inv) {
+  int E = (int)((amax_bits >> 23) & 0xffu);
+  E = E < 14 ? 14 : (E > 253 ? 253 : E);
+  scale = __uint_as_float((uint32_t)(267 - E) << 23);
+  inv = __uint_as_float((uint32_t)(E - 13) << 23);
+}
+// 8 floats (already scaled) -> hi and mid fragments of 8 fp16.  (Scalars, not a 2-vector of packed words: hipcc 7.2 folds
+// bit_cast<f16x2>(v[1]) of a uint2 to v[0]'s halves.)
+__device__ __forceinline__ void split8_f16(const float (&v)[8], bf16x8 (&out)[2]) {
+  uint32_t h[4], m[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t hh = pack_f16(v[2 * i], v[2 * i + 1]);
+    const f32x2 f = __builtin_convertvector(__builtin_bit_cast(f16x2, hh), f32x2);
+    h[i] = hh;
+    m[i] = pack_f16(v[2 * i] - f[0], v[2 * i + 1] - f[1]);
+  }
+  out[0] = __builtin_bit_cast(bf16x8, u32x4{h[0], h[1], h[2], h[3]});
+  out[1] = __builtin_bit_cast(bf16x8, u32x4{m[0], m[1], m[2], m[3]});
+}
+__device__ __forceinline__ f32x16 products_f16(const bf16x8 (&a)[2], const bf16x8 (&b)[2], f32x16 c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[1]), __builtin_bit_cast(f16x8, b[0]), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, b[1]), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, b[0]), c, 0, 0, 0);
+  return c;
+}
+
+// stage_tile with the tile's values scaled by `sc` (a power of two) and split into fp16 hi / mid images
+template <bool RM, bool TR>
+__device__ __forceinline__ void stage_tile_f16(char* __restrict__ rm, char* __restrict__ tr, const f32x4 (&r)[4], float sc) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = (int)threadIdx.x + 256 * i;
+    const int row = e >> 4, d4 = e & 15;
+    const float x0 = r[i][0] * sc, x1 = r[i][1] * sc, x2 = r[i][2] * sc, x3 = r[i][3] * sc;
+    const uint32_t h0 = pack_f16(x0, x1), h1 = pack_f16(x2, x3);
+    const f32x2 f0 = __builtin_convertvector(__builtin_bit_cast(f16x2, h0), f32x2);
+    const f32x2 f1 = __builtin_convertvector(__builtin_bit_cast(f16x2, h1), f32x2);
+    const uint32_t m0 = pack_f16(x0 - f0[0], x1 - f0[1]), m1 = pack_f16(x2 - f1[0], x3 - f1[1]);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const uint32_t p0 = t ? m0 : h0, p1 = t ? m1 : h1;
+      if (RM) *reinterpret_cast<u32x2*>(rm + t * kImg + row * 128 + (((d4 >> 1) ^ ((row >> 1) & 7)) << 4) + (d4 & 1) * 8) = u32x2{p0, p1};
+      if (TR) {
+        const int d = 4 * d4;
+        char* q = tr + t * kImg + (row & 3) * 2;
+        const int slot = row >> 2;
+        *reinterpret_cast<uint16_t*>(q + (d + 0) * 128 + ((slot ^ (((d + 0) >> 1) & 15)) << 3)) = (uint16_t)(p0 & 0xffffu);
+        *reinterpret_cast<uint16_t*>(q + (d + 1) * 128 + ((slot ^ (((d + 1) >> 1) & 15)) << 3)) = (uint16_t)(p0 >> 16);
+        *reinterpret_cast<uint16_t*>(q + (d + 2) * 128 + ((slot ^ (((d + 2) >> 1) & 15)) << 3)) = (uint16_t)(p1 & 0xffffu);
+        *reinterpret_cast<uint16_t*>(q + (d + 3) * 128 + ((slot ^ (((d + 3) >> 1) & 15)) << 3)) = (uint16_t)(p1 >> 16);
+      }
+    }
+  }
+}
+
+// a lane's 32 head-dim values times `mul`, scaled by the ROW's own power of two (both halves of the row agree on it through
+// one shuffle) and split; returns the inverse scale and the row's max |value * mul|
+__device__ __forceinline__ void load_row_frag_f16(const float* __restrict__ base, int64_t row_stride, int row, int half, float mul,
+                                                  RowFrag<2>& out, float& inv, float& amax) {
+  const float* p = base + (int64_t)row * row_stride + 32 * half;
+  f32x4 a[8];
+  uint32_t mb = 0;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    a[s] = *reinterpret_cast<const f32x4*>(p + 4 * s);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      a[s][e] *= mul;
+      const uint32_t b = __float_as_uint(a[s][e]) & 0x7fffffffu;
+      mb = b > mb ? b : mb;
+    }
+  }
+  const uint32_t other = (uint32_t)__shfl_xor((int)mb, 32, 64);
+  mb = other > mb ? other : mb;
+  float sc;
+  attn_pow2_scale(mb, sc, inv);
+  amax = __uint_as_float(mb);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const float v[8] = {a[2 * s][0] * sc, a[2 * s][1] * sc, a[2 * s][2] * sc, a[2 * s][3] * sc,
+                        a[2 * s + 1][0] * sc, a[2 * s + 1][1] * sc, a[2 * s + 1][2] * sc, a[2 * s + 1][3] * sc};
+    split8_f16(v, out.f[s]);
+  }
+}
+
+__device__ __forceinline__ f32x16 rm_times_frag_f16(const char* __restrict__ rm, int rb, int lane, const RowFrag<2>& q, f32x16 acc) {
+  const int row = 32 * rb + (lane & 31), half = lane >> 5;
+  const char* p = rm + row * 128;
+  const int sw = (row >> 1) & 7;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    bf16x8 a[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) a[t] = *reinterpret_cast<const bf16x8*>(p + t * kImg + (((4 * half + s) ^ sw) << 4));
+    acc = products_f16(a, q.f[s], acc);
+  }
+  return acc;
+}
+
+// tr_times_acc with the accumulator operand multiplied by `bsc` (a power of two) before the split
+__device__ __forceinline__ void tr_times_acc_f16(const char* __restrict__ tr, int rb, int lane, const f32x16& x, float bsc, f32x16& o0,
+                                                 f32x16& o1) {
+  const int half = lane >> 5;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = x[8 * u + j] * bsc;
+    bf16x8 b[2];
+    split8_f16(v, b);
+    const int slot = 8 * rb + 4 * u + half;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const int d = 32 * dt + (lane & 31);
+      const char* p = tr + d * 128;
+      const int sw = (d >> 1) & 15;
+      bf16x8 a[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const u32x2 lo = *reinterpret_cast<const u32x2*>(p + t * kImg + ((slot ^ sw) << 3));
+        const u32x2 hi = *reinterpret_cast<const u32x2*>(p + t * kImg + (((slot + 2) ^ sw) << 3));
+        a[t] = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
+      }
+      if (dt == 0)
+        o0 = products_f16(a, b, o0);
+      else
+        o1 = products_f16(a, b, o1);
+    }
+  }
+}
+
+// float bits of max |q|, |k|, |v|, |dO| over the T rows of every (image, head): out[(b H + h) 4 + {0, 1, 2, 3}]
+__global__ __launch_bounds__(256) void attn_amax_bh_kernel(AttnPtrsB p, int T, int H, const float* __restrict__ go,
+                                                           uint32_t* __restrict__ out) {
+  const int b = blockIdx.y, h = blockIdx.x;
+  const float* src[4] = {p.q + (int64_t)b * p.sb + (int64_t)h * p.sh, p.k + (int64_t)b * p.sb + (int64_t)h * p.sh,
+                         p.v + (int64_t)b * p.sb + (int64_t)h * p.sh, go + ((int64_t)b * T) * (H * kD) + h * kD};
+  const int64_t stride[4] = {p.st, p.st, p.st, (int64_t)H * kD};
+  uint32_t m[4] = {0, 0, 0, 0};
+  const int d4 = threadIdx.x & 15;
+  for (int row = threadIdx.x >> 4; row < T; row += 16) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src[w] + (int64_t)row * stride[w] + 4 * d4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t bits = __float_as_uint(v[e]) & 0x7fffffffu;
+        m[w] = bits > m[w] ? bits : m[w];
+      }
+    }
+  }
+  __shared__ uint32_t part[4][4];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t other = (uint32_t)__shfl_xor((int)m[w], o, 64);
+      m[w] = other > m[w] ? other : m[w];
+    }
+    if ((threadIdx.x & 63) == 0) part[w][threadIdx.x >> 6] = m[w];
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const int w = threadIdx.x;
+    uint32_t r = part[w][0];
+    for (int i = 1; i < 4; ++i) r = part[w][i] > r ? part[w][i] : r;
+    out[((int64_t)b * H + h) * 4 + w] = r;
+  }
+}
+
+// ---- dQ, fp16 x 2 ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_dq_f16_kernel(AttnPtrsB p, int T, int H, float scale, const float* __restrict__ go,
+                                                             const float* __restrict__ lse, const float* __restrict__ delta,
+                                                             const uint32_t* __restrict__ amax_bh, float* __restrict__ dq,
+                                                             int64_t gsb, int64_t gsh, int64_t gst) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dq16[];
+  char* k_rm = smem_dq16;
+  char* k_tr = k_rm + 2 * kImg;
+  char* v_rm = k_tr + 2 * kImg;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+  const int q_row = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const bool q_ok = q_row < T;
+  const int q_ld = q_ok ? q_row : T - 1;
+  const float* qb = p.q + (int64_t)b * p.sb + (int64_t)h * p.sh;
+  const float* kb = p.k + (int64_t)b * p.sb + (int64_t)h * p.sh;
+  const float* vb = p.v + (int64_t)b * p.sb + (int64_t)h * p.sh;
+  const uint32_t* aw = amax_bh + ((int64_t)b * H + h) * 4;
+  float sK, invK, sV, invV;
+  attn_pow2_scale(aw[1], sK, invK);
+  attn_pow2_scale(aw[2], sV, invV);
+  RowFrag<2> qf, gf;
+  float inv_q, inv_g, amax_q, amax_g;
+  load_row_frag_f16(qb, p.st, q_ld, half, scale * kLog2e, qf, inv_q, amax_q);
+  load_row_frag_f16(go + ((int64_t)b * T) * (H * kD) + h * kD, (int64_t)H * kD, q_ld, half, 1.f, gf, inv_g, amax_g);
+  // |dS| <= (|dP| + |delta|) scale <= 2 x 64 max|dO_i| max|V| scale
+  float s_ds, inv_ds;
+  attn_pow2_scale(__float_as_uint(128.f * amax_g * __uint_as_float(aw[2]) * scale), s_ds, inv_ds);
+  const float c_s = invK * inv_q, c_dp = invV * inv_g;
+  const float lse2 = lse[((int64_t)b * H + h) * T + q_ld] * kLog2e;
+  const float dlt = delta[((int64_t)b * H + h) * T + q_ld];
+  f32x16 dq0 = zero16(), dq1 = zero16();
+  const int n_tiles = (T + kTile - 1) / kTile;
+  f32x4 kr[4], vr[4];
+  load_tile_regs(kb, p.st, 0, T, kr);
+  load_tile_regs(vb, p.st, 0, T, vr);
+  for (int j = 0; j < n_tiles; ++j) {
+    __syncthreads();
+    stage_tile_f16<true, true>(k_rm, k_tr, kr, sK);
+    stage_tile_f16<true, false>(v_rm, nullptr, vr, sV);
+    __syncthreads();
+    if (j + 1 < n_tiles) {
+      load_tile_regs(kb, p.st, (j + 1) * kTile, T, kr);
+      load_tile_regs(vb, p.st, (j + 1) * kTile, T, vr);
+    }
+    if (blockIdx.x * 128 + wave * 32 >= T) continue;
+    const int key0 = j * kTile;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      f32x16 s = rm_times_frag_f16(k_rm, rb, lane, qf, zero16());    // S^T sK sq (log2 domain)
+      f32x16 dp = rm_times_frag_f16(v_rm, rb, lane, gf, zero16());   // dP^T sV sg
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const bool exists = key0 + 32 * rb + acc_row(t, half) < T;
+        const float pr = exists ? fast_exp2(s[t] * c_s - lse2) : 0.f;
+        s[t] = pr * (dp[t] * c_dp - dlt) * scale;                      // dS^T
+      }
+      tr_times_acc_f16(k_tr, rb, lane, s, s_ds, dq0, dq1);             // dQ^T sK s_ds += K^T dS^T
+    }
+  }
+  store_rows_t(dq + (int64_t)b * gsb + (int64_t)h * gsh, gst, q_row, q_ok, lane, dq0, dq1, invK * inv_ds);
+}
+
+// ---- dK, dV, fp16 x 2 --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_dkv_f16_kernel(AttnPtrsB p, int T, int H, float scale, const float* __restrict__ go,
+                                                              const float* __restrict__ lse, const float* __restrict__ delta,
+                                                              const uint32_t* __restrict__ amax_bh, float* __restrict__ dk,
+                                                              float* __restrict__ dv, int64_t gsb, int64_t gsh, int64_t gst) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dkv16[];
+  char* q_rm = smem_dkv16;
+  char* q_tr = q_rm + 2 * kImg;
+  char* g_rm = q_tr + 2 * kImg;
+  char* g_tr = g_rm + 2 * kImg;
+  float* lse_s = reinterpret_cast<float*>(g_tr + 2 * kImg);
+  float* dlt_s = lse_s + kTile;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+  const int k_row = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const bool k_ok = k_row < T;
+  const int k_ld = k_ok ? k_row : T - 1;
+  const float* qb = p.q + (int64_t)b * p.sb + (int64_t)h * p.sh;
+  const float* kb = p.k + (int64_t)b * p.sb + (int64_t)h * p.sh;
+  const float* vb = p.v + (int64_t)b * p.sb + (int64_t)h * p.sh;
+  const float* gb = go + ((int64_t)b * T) * (H * kD) + h * kD;
+  const int64_t gst_o = (int64_t)H * kD;
+  const uint32_t* aw = amax_bh + ((int64_t)b * H + h) * 4;
+  float sQ, invQ, sG, invG;
+  attn_pow2_scale(aw[0], sQ, invQ);
+  attn_pow2_scale(aw[3], sG, invG);
+  RowFrag<2> kf, vf;
+  float inv_k, inv_v, amax_k, amax_v;
+  load_row_frag_f16(kb, p.st, k_ld, half, scale * kLog2e, kf, inv_k, amax_k);
+  load_row_frag_f16(vb, p.st, k_ld, half, 1.f, vf, inv_v, amax_v);
+  // |dS| <= 2 x 64 max|dO| max|V| scale over the (image, head): the delta of a query is not bounded by THIS key's V row
+  float s_ds, inv_ds;
+  attn_pow2_scale(__float_as_uint(128.f * __uint_as_float(aw[3]) * __uint_as_float(aw[2]) * scale), s_ds, inv_ds);
+  const float s_p = 16384.f, inv_p = 1.f / 16384.f;                   // P <= 1
+  const float c_s = invQ * inv_k, c_dp = invG * inv_v;
+  f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
+  const int n_tiles = (T + kTile - 1) / kTile;
+  for (int j = 0; j < n_tiles; ++j) {
+    f32x4 qr[4], gr[4];
+    load_tile_regs(qb, p.st, j * kTile, T, qr);
+    load_tile_regs(gb, gst_o, j * kTile, T, gr);
+    __syncthreads();
+    stage_tile_f16<true, true>(q_rm, q_tr, qr, sQ);
+    stage_tile_f16<true, true>(g_rm, g_tr, gr, sG);
+    if (threadIdx.x < kTile) {
+      const int qq = j * kTile + (int)threadIdx.x;
+      const int ql = qq < T ? qq : T - 1;
+      lse_s[threadIdx.x] = lse[((int64_t)b * H + h) * T + ql] * kLog2e;
+      dlt_s[threadIdx.x] = delta[((int64_t)b * H + h) * T + ql];
+    }
+    __syncthreads();
+    if (blockIdx.x * 128 + wave * 32 >= T) continue;
+    const int q0 = j * kTile;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      f32x16 pr = rm_times_frag_f16(q_rm, rb, lane, kf, zero16());   // S sQ sk
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int ql = 32 * rb + acc_row(t, half);
+        const bool exists = (q0 + ql < T) && k_ok;
+        pr[t] = exists ? fast_exp2(pr[t] * c_s - lse_s[ql]) : 0.f;    // P
+      }
+      tr_times_acc_f16(g_tr, rb, lane, pr, s_p, dv0, dv1);            // dV^T sG s_p += dO^T P
+      f32x16 dp = rm_times_frag_f16(g_rm, rb, lane, vf, zero16());   // dP sG sv
+#pragma unroll
+      for (int t = 0; t < 16; ++t) pr[t] = pr[t] * (dp[t] * c_dp - dlt_s[32 * rb + acc_row(t, half)]) * scale;   // dS
+      tr_times_acc_f16(q_tr, rb, lane, pr, s_ds, dk0, dk1);           // dK^T sQ s_ds += Q^T dS
+    }
+  }
+  store_rows_t(dk + (int64_t)b * gsb + (int64_t)h * gsh, gst, k_row, k_ok, lane, dk0, dk1, invQ * inv_ds);
+  store_rows_t(dv + (int64_t)b * gsb + (int64_t)h * gsh, gst, k_row, k_ok, lane, dv0, dv1, invG * inv_p);
+}
+
 }  // namespace sea
 
 using namespace sea;
@@ -452,5 +781,27 @@ int sea_attention_bwd_bf16(const float* q, const float* k, const float* v, int64
     hipLaunchKernelGGL(attn_dq_bf16_kernel<2>, grid, block, (size_t)3 * 2 * kImg, stream, p, T, H, scale, grad_out, lse, delta, dq, gsb, gsh, gst);
     hipLaunchKernelGGL(attn_dkv_bf16_kernel<2>, grid, block, lds, stream, p, T, H, scale, grad_out, lse, delta, dk, dv, gsb, gsh, gst);
   }
+  return (int)hipGetLastError();
+}
+
+// fp16 x 2 backward: amax_ws = 4 B H device words of scratch (filled here)
+int sea_attention_bwd_f16x2(const float* q, const float* k, const float* v, int64_t sb, int64_t sh, int64_t st, int B, int H, int T,
+                            float scale, const float* grad_out, const float* lse, const float* delta, uint32_t* amax_ws, float* dq,
+                            float* dk, float* dv, int64_t gsb, int64_t gsh, int64_t gst, hipStream_t stream) {
+  AttnPtrsB p{q, k, v, sb, sh, st};
+  dim3 grid((T + 127) / 128, H, B), block(256);
+  const size_t lds_dkv = (size_t)4 * 2 * kImg + 2 * kTile * sizeof(float), lds_dq = (size_t)3 * 2 * kImg;
+  static bool attr_set_dev[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!attr_set_dev[dev & 63]) {
+    (void)hipFuncSetAttribute((const void*)attn_dkv_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv);
+    (void)hipFuncSetAttribute((const void*)attn_dq_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
+    attr_set_dev[dev & 63] = true;
+  }
+  hipLaunchKernelGGL(attn_amax_bh_kernel, dim3(H, B), block, 0, stream, p, T, H, grad_out, amax_ws);
+  hipLaunchKernelGGL(attn_dq_f16_kernel, grid, block, lds_dq, stream, p, T, H, scale, grad_out, lse, delta, amax_ws, dq, gsb, gsh, gst);
+  hipLaunchKernelGGL(attn_dkv_f16_kernel, grid, block, lds_dkv, stream, p, T, H, scale, grad_out, lse, delta, amax_ws, dk, dv, gsb, gsh,
+                     gst);
   return (int)hipGetLastError();
 }

@@ -75,6 +75,8 @@ _SIGS = {
                                _i64, _i64, _i64, _vp]),
     "sea_attention_bwd_terms": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _i64, _i64, _i64, _i, _vp]),
+    "sea_attention_bwd_f16": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                   _i64, _i64, _i64, _vp]),
     "sea_absmax_bits": (_i, [_vp, _i64, _i, _i, _i, _i64, _i, _vp, _vp]),
     "sea_gemm_split_f16": (_i, [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _i, _i64, _i64, _i64, _vp, _i, _vp, _vp]),
     "sea_wino_input_transform_amax": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -666,9 +668,26 @@ def attention_qkv(qkv, scale: float):
     return out, lse
 
 
+ATTN_TERMS_BWD_DEFAULT = 22
+
+
+def attn_terms_bwd() -> int:
+    """Arithmetic of the attention backward products, the ONE place Python callers read it: env SEA_ATTN_TERMS_BWD (looked up per
+    call: tests switch it in-process) or 22.  22 = fp16 x 2 (22 significant bits per operand, three MFMA products per pair);
+    3 / 2 = bf16 terms per operand (six / three products); 0 = the fp32 MFMA kernels."""
+    t = int(os.environ.get("SEA_ATTN_TERMS_BWD", ATTN_TERMS_BWD_DEFAULT))
+    return t if t in (0, 2, 3, 22) else ATTN_TERMS_BWD_DEFAULT
+
+
+def attn_terms_fwd() -> int:
+    """forward products (read by the library per call): env SEA_ATTN_TERMS or 3 bf16 terms per operand; 0 = fp32 MFMA"""
+    t = int(os.environ.get("SEA_ATTN_TERMS", 3))
+    return t if t in (2, 3) else 0
+
+
 def attention_qkv_backward(qkv, out, lse, grad_out, scale: float, terms=None):
-    """gradient w.r.t. the packed qkv tensor.  ``terms``: bf16 terms of the backward products (3, 2, 0 = fp32 MFMA);
-    None = the library default (2, or SEA_ATTN_TERMS_BWD)."""
+    """gradient w.r.t. the packed qkv tensor.  ``terms``: arithmetic of the backward products (22 = fp16 x 2, 3 / 2 = bf16 terms,
+    0 = fp32 MFMA); None = ``attn_terms_bwd()``."""
     _dev(qkv, out, lse, grad_out)
     B, T, _, H, D = qkv.shape
     grad_out = _f32c(grad_out.contiguous())
@@ -676,12 +695,15 @@ def attention_qkv_backward(qkv, out, lse, grad_out, scale: float, terms=None):
     delta = torch.empty_like(lse)
     p, g = qkv.data_ptr(), dqkv.data_ptr()
     sb, sh, st = T * 3 * H * D, D, 3 * H * D
-    args = (p, p + 4 * H * D, p + 8 * H * D, sb, sh, st, B, H, T, D, float(scale), _p(_f32c(out)), _p(grad_out),
-            _p(_f32c(lse)), _p(delta), g, g + 4 * H * D, g + 8 * H * D, sb, sh, st)
-    if terms is None:
-        _check(lib().sea_attention_bwd(*args, _stream()), "sea_attention_bwd")
+    terms = attn_terms_bwd() if terms is None else int(terms)
+    head = (p, p + 4 * H * D, p + 8 * H * D, sb, sh, st, B, H, T, D, float(scale), _p(_f32c(out)), _p(grad_out),
+            _p(_f32c(lse)), _p(delta))
+    tail = (g, g + 4 * H * D, g + 8 * H * D, sb, sh, st)
+    if terms == 22:
+        ws = torch.empty(4 * B * H, dtype=torch.int32, device=qkv.device)     # max |q|, |k|, |v|, |dO| per (image, head)
+        _check(lib().sea_attention_bwd_f16(*head, _p(ws), *tail, _stream()), "sea_attention_bwd_f16")
     else:
-        _check(lib().sea_attention_bwd_terms(*args, int(terms), _stream()), "sea_attention_bwd_terms")
+        _check(lib().sea_attention_bwd_terms(*head, *tail, terms, _stream()), "sea_attention_bwd_terms")
     return dqkv
 
 

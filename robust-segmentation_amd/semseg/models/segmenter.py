@@ -44,7 +44,6 @@ class LayerNorm(nn.LayerNorm):
 
 
 USE_HIP_ATTENTION = True
-ATTN_TERMS_BWD = int(os.environ.get("SEA_ATTN_TERMS_BWD", "3"))
 
 
 class _AttentionHip(torch.autograd.Function):
@@ -65,9 +64,10 @@ class _AttentionHip(torch.autograd.Function):
     def backward(ctx, g):
         from .. import _native as N
         qkv, out, lse = ctx.saved_tensors
-        # three bf16 terms per operand = the fp32 operands exactly (training AND attack: the evaluation is fp32-equivalent
-        # like the reference's); SEA_ATTN_TERMS_BWD=2 selects round 3's two-term mode (an attack only consumes the sign)
-        return N.attention_qkv_backward(qkv, out, lse, g, ctx.scale, terms=3 if ctx.train else ATTN_TERMS_BWD), None, None
+        # training: three bf16 terms per operand (the fp32 operands exactly); attack: N.attn_terms_bwd() -- fp16 x 2 by default
+        # (22 significant bits per operand like every frozen-weight GEMM of the evaluation, at half the matrix work of three
+        # bf16 terms); SEA_ATTN_TERMS_BWD = 3 / 2 / 0 select the other modes
+        return N.attention_qkv_backward(qkv, out, lse, g, ctx.scale, terms=3 if ctx.train else None), None, None
 
 
 class Attention(nn.Module):

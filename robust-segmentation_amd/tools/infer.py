@@ -200,8 +200,11 @@ def arithmetic_mode():
     from semseg.models import convnext_upernet as M
     names = {22: "fp16x2 (22 significant bits)", 3: "bf16x3 (24 bits)", 2: "bf16x2 (16 bits)", 0: "hipBLASLt fp32"}
     fwd = M.GEMM_TERMS
+    from semseg import _native as N
     return {"gemm_forward": names.get(fwd, str(fwd)), "gemm_input_gradient": names.get(M._bwd_terms(fwd) if fwd else 0, "?"),
-            "winograd_tile": M.WINOGRAD_TILE, "accumulate": "fp32", "storage": "fp32"}
+            "winograd_tile": M.WINOGRAD_TILE, "accumulate": "fp32", "storage": "fp32",
+            # (Segmenter only) M7b attention: bf16 terms per operand, 22 = fp16 x 2, 0 = fp32 MFMA
+            "attention_forward_terms": N.attn_terms_fwd(), "attention_input_gradient_terms": N.attn_terms_bwd()}
 
 
 def _pin(t):

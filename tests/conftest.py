@@ -27,6 +27,33 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+# Suite budget (round 5): the driver gives `pytest -m gpu` 1200 s.  No single GPU test of the default selection may take more
+# than SEA_TEST_MAX_SECONDS (default 75; the builder's full-set runs use SEA_MIOU_FULL=1, which lifts it): a test that creeps past
+# it fails HERE, by name, instead of taking the whole suite's evidence with it by timeout at the end of a round.
+_MAX_S = float(os.environ.get("SEA_TEST_MAX_SECONDS", "0" if os.environ.get("SEA_MIOU_FULL") == "1" else "75"))
+DURATIONS = {}
+
+
+@pytest.hookimpl(wrapper=True)
+def pytest_runtest_call(item):
+    import time
+    t0 = time.perf_counter()
+    res = yield
+    dt = time.perf_counter() - t0
+    DURATIONS[item.nodeid] = dt
+    if _MAX_S > 0 and "gpu" in item.keywords and dt > _MAX_S:
+        pytest.fail(f"{item.nodeid} took {dt:.0f} s: over the {_MAX_S:.0f} s budget of a GPU test (tests/conftest.py)", pytrace=False)
+    return res
+
+
+def pytest_terminal_summary(terminalreporter):
+    if DURATIONS:
+        total = sum(DURATIONS.values())
+        worst = sorted(DURATIONS.items(), key=lambda kv: -kv[1])[:5]
+        terminalreporter.write_line(f"[suite budget] {total:.0f} s in test bodies; slowest: "
+                                    + "; ".join(f"{k.split('::')[-1]} {v:.0f} s" for k, v in worst))
+
+
 def load_golden(name):
     d = np.load(os.path.join(GOLDEN, name + ".npz"))
     out = {}

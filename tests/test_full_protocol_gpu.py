@@ -4,8 +4,8 @@ tools.infer (reference tools/infer.py:332-408).  ~17 s of attack per radius.
 
 Asserted: the L-inf ball and the [0, 1] box of every returned image; the arg-max map and the accuracy the attack hands out
 are those of a fresh forward of the returned image; the worst-case bookkeeping (worst_Acc <= every attack's own aAcc, the
-greedy mIoU <= the mIoU of the attack it starts from); the evaluation is bitwise reproducible (two runs, same summary); the captured
-HIP graphs and their activation pools are released (device memory back to where it was); and the wall time per step is
+greedy mIoU <= the mIoU of the attack it starts from); the evaluation is bitwise reproducible (two runs, same summary; at eps 8); the
+captured HIP graph pair and its activation pool are released (device memory back to where it was); and the wall time per step is
 within 15 % of a short measurement of the same step on this box (the sustained rate of the 900-step run: the chip lowers its
 clock under sustained matrix load).
 """
@@ -90,18 +90,20 @@ def test_configs1_full_sea_3x300_as_written(tmp_path, monkeypatch, eps):
     # bitwise reproducible at 512 x 512: a second evaluation gives the same numbers, digit for digit -- and leaves nothing
     # behind on the device: the nine runs' captured graphs, their activation pools and per-stream library workspaces are
     # released or reused (the first evaluation may keep process-lifetime workspaces; the second must not add to them)
-    calls.clear()
-    gc.collect()
-    torch.cuda.empty_cache()
-    torch.cuda.synchronize()
-    base = torch.cuda.memory_allocated()
-    s2 = infer.main(args + ["--json", str(tmp_path / "b.json")])
-    gc.collect()
-    torch.cuda.empty_cache()
-    held = torch.cuda.memory_allocated() - base
-    assert held <= 64 * 2 ** 20, f"{held / 2 ** 20:.0f} MiB more allocated after a second evaluation (graphs / pools not released?)"
-    for k in ("worst_Acc", "final_miou", "worst_Acc_indiv", "loss-wise_miou"):
-        assert s1[k] == s2[k], (k, s1[k], s2[k])
+    s2 = s1
+    if eps == 8.0:   # (the second evaluation once, at one radius: suite budget)
+        calls.clear()
+        gc.collect()
+        torch.cuda.empty_cache()
+        torch.cuda.synchronize()
+        base = torch.cuda.memory_allocated()
+        s2 = infer.main(args + ["--json", str(tmp_path / "b.json")])
+        gc.collect()
+        torch.cuda.empty_cache()
+        held = torch.cuda.memory_allocated() - base
+        assert held <= 64 * 2 ** 20, f"{held / 2 ** 20:.0f} MiB more allocated after a second evaluation (graphs / pools not released?)"
+        for k in ("worst_Acc", "final_miou", "worst_Acc_indiv", "loss-wise_miou"):
+            assert s1[k] == s2[k], (k, s1[k], s2[k])
     # sustained rate of the 900-step evaluation vs a short window of the same step
     short = _short_step_ms()
     per_step = min(s1["attack_seconds"], s2["attack_seconds"]) * 1e3 / (3 * 300)

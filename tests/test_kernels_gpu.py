@@ -1070,11 +1070,12 @@ def test_counts_full_size_ade(N):
 # ------------------------------------------------------------------------------------------------ M7 attention
 @pytest.mark.parametrize("case", [(2, 6, 1025, "ViT-S/16 encoder, 512x512"), (1, 6, 1175, "mask transformer, 1024 patches + 151 classes"),
                                   (3, 2, 64, "one tile"), (1, 1, 33, "ragged"), (2, 3, 130, "two blocks, ragged")])
-@pytest.mark.parametrize("terms", [(3, 2), (3, 3), (0, 0)])
+@pytest.mark.parametrize("terms", [(3, 22), (3, 2), (3, 3), (0, 0)])
 def test_fp32_mfma_attention_forward_and_backward(N, case, terms):
     """softmax(q k^T * scale) v as written in the reference (vit_encoder.py:106-127), explicit fp32 (and an fp64 check).
-    terms = (forward, backward) bf16 terms per operand of M7b (csrc/attention_bf16.hip); (0, 0) = the fp32 MFMA kernels
-    of M7.  Shipped: (3, 2): forward and log-sum-exp at fp32 level, input gradient with 16-bit operands."""
+    terms = (forward, backward) arithmetic of M7b (csrc/attention_bf16.hip): bf16 terms per operand, 22 = fp16 x 2; (0, 0) =
+    the fp32 MFMA kernels of M7.  Shipped: (3, 22): forward and log-sum-exp at fp32 level, input gradient with 22-bit
+    operands (fp32-level: the strict bound); (3, 2) is round 3's 16-bit gradient."""
     import os
     B, H, T, _ = case
     os.environ["SEA_ATTN_TERMS"], os.environ["SEA_ATTN_TERMS_BWD"] = str(terms[0]), str(terms[1])
@@ -1118,6 +1119,42 @@ def _attention_case(N, B, H, T, strict_backward):
     # deterministic
     dq2 = N.attention_qkv_backward(dev(qkv), out, lse, dev(gout), scale)
     assert torch.equal(dq, dq2)
+
+
+def _attn_ref64(qkv, gout, scale):
+    B, T, _, H, _ = qkv.shape
+    x = qkv.double().requires_grad_(True)
+    q, k, v = x.permute(2, 0, 3, 1, 4)
+    att = ((q @ k.transpose(-2, -1)) * scale).softmax(-1)
+    y = (att @ v).transpose(1, 2).reshape(B, T, H * 64)
+    (gx,) = torch.autograd.grad(y, [x], grad_outputs=gout.double())
+    return gx
+
+
+@pytest.mark.parametrize("case", ["plain", "rows spanning orders of magnitude"])
+def test_attention_backward_fp16x2_is_as_accurate_as_three_bf16_terms(N, case):
+    """fp16 x 2 (three MFMA products per operand pair) against three bf16 terms (six products) and float64: the error of the
+    shipped backward is at the level of the exact-operand mode -- also when the gradient rows (tokens, images) and the
+    activations span many orders of magnitude, which is what the power-of-two scales per row / per (image, head) are for."""
+    g = torch.Generator().manual_seed(77)
+    B, H, T = 3, 6, 1025
+    qkv = torch.randn(B, T, 3, H, 64, generator=g)
+    gout = torch.randn(B, T, H * 64, generator=g)
+    if case != "plain":
+        gout = gout * torch.exp2(torch.randint(-20, 1, (B, T, 1), generator=g).float()) * torch.tensor([1.0, 1e-4, 1e-8]).view(B, 1, 1)
+        qkv[:, :, 2] *= torch.exp2(torch.randint(-6, 5, (B, 1, H, 1), generator=g).float())          # V per head
+        qkv[:, :, 0] *= torch.exp2(torch.randint(-3, 3, (B, T, 1, 1), generator=g).float())          # Q per token
+    scale = 64 ** -0.5
+    ref = _attn_ref64(qkv, gout, scale)
+    out, lse = N.attention_qkv(dev(qkv), scale)
+    errs = {}
+    for terms in (22, 3, 2):
+        d = N.attention_qkv_backward(dev(qkv), out, lse, dev(gout), scale, terms=terms).cpu().double()
+        # per image (their gradients differ by orders of magnitude): worst relative-to-max error over the images
+        errs[terms] = max(((d[b] - ref[b]).abs().max() / ref[b].abs().max()).item() for b in range(B))
+    print(f"\n[attention backward, {case}] max error / max|g| per image: fp16x2 {errs[22]:.2e}   bf16x3 {errs[3]:.2e}   bf16x2 {errs[2]:.2e}")
+    assert errs[22] <= max(1.5 * errs[3], 2e-7), errs
+    assert errs[22] < 0.1 * errs[2], errs
 
 
 def test_segmenter_uses_hip_attention_and_matches_sdpa(N):

@@ -56,12 +56,14 @@ def main():
             Wp = N.gemm_split_pack(W, terms=terms)
             outs = [torch.empty(G, M, Nn, device="cuda") for _ in range(2)]
             kw = dict(amax=amax, amax_rows=1) if terms == 22 else {}
-            ts = {0: [], 1: []}
+            pipes = (0, 1, 3) if (Nn % 256 == 0 and terms in (22, 2)) else (0, 1)
+            outs.append(torch.empty(G, M, Nn, device="cuda"))
+            ts = {0: [], 1: [], 3: []}
             for rnd in range(3):
-                for pipe in (0, 1):
+                for pipe in pipes:
                     L.sea_gemm_split_pipeline(pipe)
-                    ts[pipe].append(timed(lambda: N.gemm_split(A, Wp, out=outs[pipe], **kw), reps))
-            same = torch.equal(outs[0], outs[1])
+                    ts[pipe].append(timed(lambda: N.gemm_split(A, Wp, out=outs[min(pipe, 2)], **kw), reps))
+            same = torch.equal(outs[0], outs[1]) and (3 not in pipes or torch.equal(outs[0], outs[2]))
             prod = 3 if terms in (22, 2) else 1
             t0, t1 = min(ts[0]), min(ts[1])
             tot[terms, 0] = tot.get((terms, 0), 0) + t0
@@ -69,7 +71,9 @@ def main():
             print(f"{name:44s} G={G:2d} M={M:6d} K={K:4d} N={Nn:4d} terms={terms:2d}  single-stage "
                   f"{'/'.join(f'{t:7.1f}' for t in ts[0])} us ({prod * flop / t0 / 1e6:6.0f} TF/s)   ping-pong "
                   f"{'/'.join(f'{t:7.1f}' for t in ts[1])} us ({prod * flop / t1 / 1e6:6.0f} TF/s)   x{t0 / t1:.2f}  "
+                  + (f"256x256 {'/'.join(f'{t:7.1f}' for t in ts[3])} us ({prod * flop / min(ts[3]) / 1e6:6.0f} TF/s) x{t0 / min(ts[3]):.2f}  " if ts[3] else "") +
                   f"bits {'EQUAL' if same else 'DIFFER'}", flush=True)
+            del outs
         del A, W
     L.sea_gemm_split_pipeline(1)
     for terms in terms_list:

@@ -42,6 +42,7 @@ SOURCES = [
     ("attention.hip", []),
     ("attention_bf16.hip", []),
     ("gemm_split.hip", []),
+    ("gemm_split_big.hip", ["-fno-slp-vectorize"]),
     ("gemm_split_pp.hip", ["-fno-slp-vectorize"]),   # (packed f32 VALU beside MFMAs costs issue time: MI355X guide)
     ("greedy_host.cpp", ["-ffp-contract=off"]),
     ("api_misc.cpp", []),

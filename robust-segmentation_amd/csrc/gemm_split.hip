@@ -569,7 +569,7 @@ static std::atomic<int> g_mfma_shape{[] {
 // value only queries.  Returns the previous shape.  Results of the two shapes differ in the last bits (summation order).
 static std::atomic<int> g_pipeline{[] {
   const char* e = getenv("SEA_GEMM_PIPE");
-  return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2;
+  return (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 2;
 }()};
 
 // tuning knob: K-loop pipeline of sea_gemm_split* at one or two terms per operand: 0 = the single-stage loop (32 KB of LDS, three
@@ -579,7 +579,7 @@ static std::atomic<int> g_pipeline{[] {
 // only queries.  Returns the previous setting.  The two kernels give the SAME BITS (same split, same MFMA order).
 extern "C" int sea_gemm_split_pipeline(int pipe) {
   const int prev = g_pipeline.load(std::memory_order_relaxed);
-  if (pipe >= 0 && pipe <= 2) g_pipeline.store(pipe, std::memory_order_relaxed);
+  if (pipe >= 0 && pipe <= 3) g_pipeline.store(pipe, std::memory_order_relaxed);
   return prev;
 }
 
@@ -774,6 +774,12 @@ static int gemm_split_impl(const float* A, int64_t lda, const void* Wp, float* C
   const int pro = p.a_gelu ? 2 : (p.a_gelu_grad_of ? (p.a_gate ? 3 : 1) : 0);
   const hipStream_t st = (hipStream_t)stream;
   const int pipe = g_pipeline.load(std::memory_order_relaxed);
+  // 256 x 256 tiles (gemm_split_big.hip) for the products that are bound by the bytes a CU pulls through its L1: many tiles,
+  // N a multiple of 256, plain epilogue.  pipe 3 forces them wherever they apply, pipe 2 takes them from 1024 tiles on.
+  if (!shape16 && (terms == 22 || terms == 2) && pro == 0 && !fused && (N % 256) == 0 && M >= 256 && (pipe == 2 || pipe == 3)) {
+    const int64_t big_tiles = (int64_t)((M + 255) / 256) * (N / 256) * batch;
+    if ((pipe == 3 || big_tiles >= 1024) && gemm_split_big_launch(p, terms, batch, st)) SEA_RETURN_LAST();
+  }
   // per launch (pipe 2): the ping-pong kernel where it wins IN the attack loop (profiles/r5_gemm_pipe_ab.md): a VALU-heavy
   // prologue (GELU / GELU' / gate on A: hidden in its MFMA shadow) on a grid that fills two blocks per CU at least as
   // well as three (768 tiles are one round of three blocks per CU but one and a half of two)

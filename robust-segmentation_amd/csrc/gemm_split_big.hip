@@ -1,0 +1,337 @@
+// M8, 256 x 256 tiles for the Winograd-domain products (fp16 x 2; N a multiple of 256; thousands of tiles).
+//
+// Why a third kernel.  The knock-out timings of round 5 (profiles/r5_gemm_knockout_big.log, devtools/gemm_knockout.py) say what
+// bounds the largest launch (36 x 8192 x 512 x 512, 545 us isolated): not the MFMAs (-100 us without them), not HBM (1.28 GB =
+// the algorithmic minimum, TCC counters), but the bytes every CU pulls through its vector L1: 4.84 GB per launch = 128 x 128
+// tiles re-reading A four times and the packed weights sixty-four times out of L2 (-140 us without EITHER half of the loads).
+// A 128 x 128 x 32 step needs 32 KB of loads for 768 MFMA cycles per SIMD: 42 B/clk/CU of a 64 B/clk path.  Only a larger tile
+// lowers that: 256 x 256 x 32 takes 64 KB for 3072 cycles, half the bytes per flop.
+//
+// Shape: 512 threads = 8 waves as 4 (M) x 2 (N), wave tile 64 x 128 (eight 32x32x16 accumulators = 128 VGPRs), two waves per
+// SIMD, ONE block per CU.  Two LDS stages of 64 KB (A: 2 terms x 256 rows x 64 B, W: the same) + 2 KB of row scales.  The K
+// loop is the ping-pong loop of gemm_split_pp.hip: one barrier per K step, the operand split of the next tile placed by hand
+// between the wave's own MFMAs, buffer loads with a zero-record descriptor past the end of K.  Same split, same MFMA order
+// per accumulator as the other two kernels: the same bits.
+#include "gemm_split.h"
+
+namespace sea {
+
+constexpr int BG_BM = 256, BG_BN = 256;
+constexpr int BG_IMG = BG_BM * GS_BK * 2;   // bytes of one term image: 256 rows x 64 B
+
+template <bool F16>
+__global__ __launch_bounds__(512, 2) void gemm_split_big_kernel(const GemmSplitArgs p) {
+  constexpr int TERMS = 2;
+  constexpr int STAGE = 2 * TERMS * BG_IMG;            // 64 KB: A images, then W images
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* const row_sc = (float*)(smem + 2 * STAGE);
+  float* const row_inv = row_sc + BG_BM;
+
+  const int M = p.M, N = p.N, K = p.K, Npad = p.Npad;
+  const int64_t lda = p.lda, ldc = p.ldc;
+  const int logical = (int)(blockIdx.x & 7) * p.per_xcd + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= p.per_xcd || logical >= p.total) return;
+  const int nb = logical % p.nblocks;
+  const int t2 = logical / p.nblocks;
+  const int mb = t2 % p.mblocks;
+  const int g = t2 / p.mblocks;
+  const int m0 = mb * BG_BM, n0 = nb * BG_BN;
+  const float* const w_inv = F16 ? (const float*)((const char*)p.w_inv + (int64_t)g * p.strideW) : nullptr;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int q = tid & 7, arow = tid >> 3;              // A staging: float4 column q of rows arow + 64 i
+
+  const char* const Abase = (const char*)(p.A + (int64_t)g * p.strideA);
+  const float* const bias = p.bias;
+  const int nkb = K / GS_BK;
+  const char* const Wbase = p.W + (int64_t)g * p.strideW + (int64_t)n0 * 64;
+  const int64_t w_term = (int64_t)Npad * 64, w_kb = (int64_t)TERMS * w_term;
+  const uint32_t woff = (uint32_t)tid * 16;
+  const uint32_t a_bytes = (uint32_t)((((int64_t)(M - 1)) * lda + K) * 4);
+  const uint32_t w_bytes = (uint32_t)((int64_t)nkb * w_kb - (int64_t)n0 * 64);
+
+  float a_sc[4] = {1.f, 1.f, 1.f, 1.f};
+  // One VGPR per address family (the K loop has no register to spare): rows arow + 64 i of A share their swizzle (64 rows
+  // further = the same (row >> 2) & 3), so their LDS offsets differ by 4096 i and their global offsets by a SCALAR 64 i lda
+  // (a row past M takes the descriptor's size as its lane offset: out of range whatever the hardware adds to it -> zeros); the four weight pieces of a thread
+  // (tid + 512 i) share theirs too.
+  const uint32_t aoff0 = (uint32_t)(((int64_t)(m0 + arow) * lda + 4 * q) * 4);
+  const uint32_t a_wr0 = (uint32_t)(arow * 64 + swz<false>(arow, q >> 1) + (q & 1) * 8);
+  const int wrow0 = tid >> 2;
+  const uint32_t w_wr0 = (uint32_t)(TERMS * BG_IMG + wrow0 * 64 + swz<false>(wrow0, tid & 3));
+  const int a_row_step = (int)(64 * lda * 4);          // bytes between rows arow + 64 i (lda < 2^23: checked by the launcher)
+  const int ra = wm * 64 + r, rb = wn * 128 + r;
+  const uint32_t a_rd = (uint32_t)(ra * 64 + swz<false>(ra, h));                 // mi: + 2048, s: ^ 32, term: + BG_IMG
+  const uint32_t b_rd = (uint32_t)(TERMS * BG_IMG + rb * 64 + swz<false>(rb, h));   // ni: + 2048
+
+  f32x4 Ra[4] = {};
+  u32x4 Rw[4] = {};
+  auto fetch_a = [&](int kb) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)Abase, 0, kb < nkb ? (int)a_bytes : 0, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      Ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+          rs, (int)((m0 + arow + 64 * i < M) ? aoff0 : a_bytes), kb * (GS_BK * 4) + i * a_row_step, 0));   // (rows past M: out of range -> zeros)
+  };
+  auto fetch_w = [&](int kb) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)Wbase, 0, kb < nkb ? (int)w_bytes : 0, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)   // pieces tid + 512 i: term i >> 1, bytes (i & 1) * 8192 + 16 tid of the term's 16 KB
+      Rw[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                            rs, (int)woff, kb * (int)w_kb + (i >> 1) * (int)w_term + (i & 1) * 8192, 0));
+  };
+
+  // staging micro-units of A row i (see gemm_split_pp.hip): (0) scale + first term, (1) remainder, (2) second term + writes
+  f32x4 sv;
+  uint32_t hi_a, hi_b;
+  auto unit_a = [&](int i, int part, char* stage) __attribute__((always_inline)) {
+    if (part == 0) {
+      f32x4 v = Ra[i];
+      if constexpr (F16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= a_sc[i];
+        hi_a = pack_f16(v[0], v[1]);
+        hi_b = pack_f16(v[2], v[3]);
+      } else {
+        hi_a = pack_bf16(v[0], v[1]);
+        hi_b = pack_bf16(v[2], v[3]);
+      }
+      sv = v;
+    } else if (part == 1) {
+      if constexpr (F16) {
+        const f32x2 f0 = __builtin_convertvector(__builtin_bit_cast(f16x2, hi_a), f32x2);
+        const f32x2 f1 = __builtin_convertvector(__builtin_bit_cast(f16x2, hi_b), f32x2);
+        sv[0] -= f0[0];
+        sv[1] -= f0[1];
+        sv[2] -= f1[0];
+        sv[3] -= f1[1];
+      } else {
+#pragma clang fp contract(off)
+        sv[0] -= __uint_as_float(hi_a << 16);
+        sv[1] -= __uint_as_float(hi_a & 0xffff0000u);
+        sv[2] -= __uint_as_float(hi_b << 16);
+        sv[3] -= __uint_as_float(hi_b & 0xffff0000u);
+      }
+    } else {
+      *(u32x2*)(stage + a_wr0 + 4096 * i) = u32x2{hi_a, hi_b};
+      const u32x2 mid = F16 ? u32x2{pack_f16(sv[0], sv[1]), pack_f16(sv[2], sv[3])}
+                            : u32x2{pack_bf16(sv[0], sv[1]), pack_bf16(sv[2], sv[3])};
+      *(u32x2*)(stage + BG_IMG + a_wr0 + 4096 * i) = mid;
+    }
+  };
+
+  bf16x8 fa[2][TERMS], fb[4][TERMS];
+  auto read_a = [&](const char* stage, int s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int t = 0; t < TERMS; ++t) fa[mi][t] = *(const bf16x8*)(stage + ((a_rd ^ (uint32_t)(32 * s)) + mi * 2048 + t * BG_IMG));
+  };
+  auto read_b = [&](const char* stage, int s, int ni) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < TERMS; ++t) fb[ni][t] = *(const bf16x8*)(stage + ((b_rd ^ (uint32_t)(32 * s)) + ni * 2048 + t * BG_IMG));
+  };
+  auto mfma3 = [&](f32x16& c, int mi, int ni, int j) __attribute__((always_inline)) {
+    // j-th product of the chain, smallest first: (mid, hi'), (hi, mid'), (hi, hi')
+    const int ia = j == 0 ? 1 : 0, ib = j == 1 ? 1 : 0;
+    if constexpr (F16)
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[mi][ia]), __builtin_bit_cast(f16x8, fb[ni][ib]), c, 0, 0, 0);
+    else
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][ia], fb[ni][ib], c, 0, 0, 0);
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+#define SEA_PIN() __builtin_amdgcn_sched_barrier(0)
+  // One K step on stage `cur`; tile kb + 1 (in Ra / Rw) is split into `nxt`, then the registers are refilled with tile `kf`.
+  // 48 MFMAs: s = 0 carries the twelve A micro-units (one behind every second product) and prefetches the s = 1 weight
+  // fragments column by column as s = 0 releases them; s = 1 carries the weight pieces and the refill loads.
+  auto step = [&](char* cur, char* nxt, int kf) __attribute__((always_inline)) {
+    int unit = 0;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          mfma3(acc[mi][ni], mi, ni, j);
+          const int slot = (ni * 2 + mi) * 3 + j;                 // 0 .. 23
+          if ((slot & 1) == 0) {
+            unit_a(unit / 3, unit % 3, nxt);
+            ++unit;
+          }
+          SEA_PIN();
+        }
+      }
+      read_b(cur, 1, ni);                                          // column ni of s = 0 is done: its registers take s = 1
+      SEA_PIN();
+    }
+    read_a(cur, 1);
+    SEA_PIN();
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          mfma3(acc[mi][ni], mi, ni, j);
+          const int slot = (ni * 2 + mi) * 3 + j;
+          if (slot < 4) *(u32x4*)(nxt + w_wr0 + (slot >> 1) * BG_IMG + (slot & 1) * 8192) = Rw[slot];
+          if (slot == 4) fetch_a(kf);
+          if (slot == 5) fetch_w(kf);
+          SEA_PIN();
+        }
+      }
+    }
+    __syncthreads();                                               // every wave is done with `cur` and has written `nxt`
+    read_a(nxt, 0);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) read_b(nxt, 0, ni);
+    SEA_PIN();
+  };
+
+  char* const st0 = smem;
+  char* const st1 = smem + STAGE;
+  // ---- prologue
+  fetch_a(0);
+  fetch_w(0);
+  if constexpr (F16) {
+    if (tid < BG_BM) {
+      int row = m0 + tid;
+      row = row < M ? row : M - 1;
+      float sc, inv;
+      uint32_t word = p.amax_bits[p.amax_rows > 0 ? row / p.amax_rows : 0];
+      const float mul = p.amax_mul_dev ? *p.amax_mul_dev : p.amax_mul;
+      if (mul != 1.f) word = __float_as_uint(__uint_as_float(word) * mul) & 0x7fffffffu;
+      pow2_scale(word, sc, inv);
+      row_sc[tid] = sc;
+      row_inv[tid] = inv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_sc[i] = row_sc[arow + 64 * i];
+  }
+  SEA_PIN();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    unit_a(i, 0, st0);
+    unit_a(i, 1, st0);
+    unit_a(i, 2, st0);
+    *(u32x4*)(st0 + w_wr0 + (i >> 1) * BG_IMG + (i & 1) * 8192) = Rw[i];
+  }
+  fetch_a(1);
+  fetch_w(1);
+  __syncthreads();
+  read_a(st0, 0);
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) read_b(st0, 0, ni);
+  int kb = 0;
+  for (; kb + 2 <= nkb; kb += 2) {
+    step(st0, st1, kb + 2);
+    step(st1, st0, kb + 3);
+  }
+  if (kb < nkb) step(st0, st1, nkb);
+#undef SEA_PIN
+
+  // ---- epilogue: each wave turns its 64 x 128 tile through 16 KB of the idle stages, 32 rows at a time, and stores 16 bytes
+  // per lane: a wave-instruction writes two 512-byte row segments (see gemm_split.h for the 128 x 128 kernels' version)
+  // (the per-column constants are loaded HERE, not before the K loop: the loop has no register to spare, and a spill inside it
+  // is a scratch load that the in-order vmcnt makes wait for the refill loads)
+  float bv_c[4], wi_c[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int col = n0 + wn * 128 + ni * 32 + r;
+    bv_c[ni] = (bias && col < N) ? bias[col] : 0.f;
+    wi_c[ni] = (F16 && col < N) ? w_inv[col] : 1.f;
+  }
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int row0_u = m0 + (wave_u >> 1) * 64;
+  float* const Cg = p.C + (int64_t)g * p.strideC;
+  char* const scr = smem + wave_u * 16384;
+  const int lr = lane >> 5, lc = lane & 31;
+  const int col4 = n0 + wn * 128 + 4 * lc;
+  const bool vec = (((ldc | p.strideC | N) & 3) == 0) && ((((uintptr_t)p.C) & 15) == 0);
+  const int off_c = lr * (int)ldc + col4;
+  const int relu = p.relu;
+  uint32_t omax = 0;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    if (mi) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row_l = (e & 3) + 8 * (e >> 2) + 4 * h;
+        const float v = (F16 ? acc[mi][ni][e] * (row_inv[(wave_u >> 1) * 64 + mi * 32 + row_l] * wi_c[ni]) : acc[mi][ni][e]) + bv_c[ni];
+        *(float*)(scr + row_l * 512 + (ni * 32 + r) * 4) = v;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int row_u = row0_u + mi * 32 + 2 * k;
+      f32x4 v = *(const f32x4*)(scr + k * 1024 + lr * 512 + lc * 16);
+      if (row_u + lr >= M || col4 >= N) continue;
+      float* const crow = Cg + (int64_t)row_u * ldc;
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+      }
+      if (vec) {
+        *(f32x4*)(crow + off_c) = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (col4 + e < N) crow[off_c + e] = v[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t vb = (col4 + e < N) ? (__float_as_uint(v[e]) & 0x7fffffffu) : 0u;
+        omax = vb > omax ? vb : omax;
+      }
+    }
+  }
+  if (p.out_amax != nullptr) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t other = (uint32_t)__shfl_xor((int)omax, o, 64);
+      omax = other > omax ? other : omax;
+    }
+    if (lane == 0 && omax > *(volatile uint32_t*)p.out_amax) atomicMax(p.out_amax, omax);
+  }
+}
+
+// launches the 256 x 256 kernel; the caller has checked: terms 22 or 2, no prologue, no fused epilogue extras, N % 256 == 0
+bool gemm_split_big_launch(GemmSplitArgs p, int terms, int batch, hipStream_t st) {
+  if (p.ldc >= (1ll << 28) || p.lda >= (1ll << 22) || (p.N % BG_BN) != 0 || p.Npad != p.N) return false;
+  p.mblocks = (p.M + BG_BM - 1) / BG_BM;
+  p.nblocks = p.N / BG_BN;
+  const int64_t total = (int64_t)p.mblocks * p.nblocks * batch;
+  if (total >= (1ll << 30)) return false;
+  p.total = (int)total;
+  p.per_xcd = (p.total + 7) / 8;
+  constexpr int lds = 2 * 2 * 2 * BG_IMG + 2 * BG_BM * (int)sizeof(float);
+  static bool attr_set_dev[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!attr_set_dev[dev & 63]) {
+    (void)hipFuncSetAttribute((const void*)gemm_split_big_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm_split_big_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set_dev[dev & 63] = true;
+  }
+  if (terms == 22)
+    hipLaunchKernelGGL(gemm_split_big_kernel<true>, dim3(p.per_xcd * 8), dim3(512), (size_t)lds, st, p);
+  else
+    hipLaunchKernelGGL(gemm_split_big_kernel<false>, dim3(p.per_xcd * 8), dim3(512), (size_t)lds, st, p);
+  return true;
+}
+
+}  // namespace sea

@@ -520,7 +520,7 @@ def test_pingpong_pipeline_gives_the_bits_of_the_single_stage_loop(N, M, K, Nn):
         return outs
 
     L = N.lib()
-    assert L.sea_gemm_split_pipeline(-1) in (0, 1, 2)
+    assert L.sea_gemm_split_pipeline(-1) in (0, 1, 2, 3)
     prev = L.sea_gemm_split_pipeline(0)
     try:
         o0 = all_variants()
@@ -532,3 +532,38 @@ def test_pingpong_pipeline_gives_the_bits_of_the_single_stage_loop(N, M, K, Nn):
         assert torch.equal(a, o1[key]), (key, (a.float() - o1[key].float()).abs().max().item())
     ref = _ref(A, W, bias, True)
     assert (o1[22, "plain"].double() - ref).abs().max().item() <= 3e-6 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("G,M,K,Nn", [(3, 1024, 512, 512), (2, 700, 96, 256), (1, 300, 32, 768), (2, 2048, 160, 256)])
+def test_256x256_tile_kernel_gives_the_bits_of_the_128x128_kernels(N, G, M, K, Nn):
+    """sea_gemm_split_pipeline(3) (csrc/gemm_split_big.hip: 256 x 256 tiles, 8 waves, one block per CU; the Winograd-domain
+    products) against pipeline 0: same split, same MFMA order per accumulator -> the same bits, for fp16 x 2 and bf16 x 2,
+    bias / ReLU / out_amax, ragged M (rows past M load zeros through the buffer descriptor) and odd / single K-step counts"""
+    g = torch.Generator(device="cuda").manual_seed(M + K + Nn)
+    A = torch.randn(G, M, K, generator=g, device="cuda") * torch.exp2(torch.randint(-6, 3, (G, M, 1), generator=g, device="cuda").float())
+    W = torch.randn(G, Nn, K, generator=g, device="cuda") / K ** 0.5
+    bias = torch.randn(Nn, generator=g, device="cuda")
+
+    def variants():
+        outs = {}
+        for terms in (22, 2):
+            Wp = N.gemm_split_pack(W, terms=terms)
+            outs[terms, "plain"] = N.gemm_split(A, Wp, groups=1)
+            outs[terms, "bias_relu"] = N.gemm_split(A, Wp, bias=bias, relu=True, groups=1)
+        word = N.amax_word(A.device)
+        outs[22, "out_amax"] = N.gemm_split(A, N.gemm_split_pack(W, terms=22), out_amax=word, groups=1).clone()
+        outs[22, "out_amax_word"] = word.clone()
+        return outs
+
+    L = N.lib()
+    prev = L.sea_gemm_split_pipeline(0)
+    try:
+        o0 = variants()
+        assert L.sea_gemm_split_pipeline(3) == 0
+        o3 = variants()
+    finally:
+        L.sea_gemm_split_pipeline(prev)
+    for key, a in o0.items():
+        assert torch.equal(a, o3[key]), (key, (a.float() - o3[key].float()).abs().max().item())
+    ref = torch.einsum("gmk,gnk->gmn", A.double(), W.double())
+    assert (o3[22, "plain"].double() - ref).abs().max().item() <= 3e-6 * ref.abs().max().item()

@@ -360,10 +360,15 @@ int sea_attention_bwd_terms(const float* q, const float* k, const float* v, int6
                             int T, int D, float scale, const float* out, const float* grad_out, const float* lse,
                             float* delta, float* dq, float* dk, float* dv, int64_t gsb, int64_t gsh, int64_t gst,
                             int terms, void* stream);
-/* The backward with fp16 x 2 operands: 22 significant bits per operand in THREE MFMA products per pair (the accuracy of the
+/* The forward and the backward with fp16 x 2 operands: 22 significant bits per operand in THREE MFMA products per pair (the accuracy of the
  * three-term bf16 mode at the cost of the two-term one).  Power-of-two scales: the exact row maximum for a lane's own
  * Q / K / V / dO row, one per (image, head) for the staged tiles (from a pre-pass this call launches), analytic bounds for the
  * soft-max operands P and dS.  amax_ws: 4 B H uint32 words of device scratch. */
+/* sea_attention_fwd with the number of bf16 terms of the products given by the caller (3, 2, or 0 = fp32 MFMA) */
+int sea_attention_fwd_terms(const float* q, const float* k, const float* v, int64_t sb, int64_t sh, int64_t st, int B, int H,
+                            int T, int D, float scale, float* out, float* lse, int terms, void* stream);
+int sea_attention_fwd_f16(const float* q, const float* k, const float* v, int64_t sb, int64_t sh, int64_t st, int B, int H,
+                          int T, int D, float scale, uint32_t* amax_ws, float* out, float* lse, void* stream);
 int sea_attention_bwd_f16(const float* q, const float* k, const float* v, int64_t sb, int64_t sh, int64_t st, int B, int H,
                           int T, int D, float scale, const float* out, const float* grad_out, const float* lse,
                           float* delta, uint32_t* amax_ws, float* dq, float* dk, float* dv, int64_t gsb, int64_t gsh,

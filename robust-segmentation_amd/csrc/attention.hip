@@ -365,6 +365,18 @@ int sea_attention_bwd_f16x2(const float* q, const float* k, const float* v, int6
                             float scale, const float* grad_out, const float* lse, const float* delta, uint32_t* amax_ws, float* dq,
                             float* dk, float* dv, int64_t gsb, int64_t gsh, int64_t gst, hipStream_t stream);
 
+int sea_attention_fwd_f16x2(const float* q, const float* k, const float* v, int64_t sb, int64_t sh, int64_t st, int B, int H, int T,
+                            float scale, uint32_t* amax_ws, float* out, float* lse, hipStream_t stream);
+
+// the forward with fp16 x 2 operands (22 significant bits, three MFMA products per pair); amax_ws: 4 B H words of scratch
+extern "C" int sea_attention_fwd_f16(const float* q, const float* k, const float* v, int64_t sb, int64_t sh, int64_t st, int B, int H,
+                                     int T, int D, float scale, uint32_t* amax_ws, float* out, float* lse, void* stream) {
+  SEA_CHECK_ARG(q && k && v && out && lse && amax_ws && B > 0 && H > 0 && T > 0 && D == kD);
+  SEA_CHECK_ARG((sb % 4) == 0 && (sh % 4) == 0 && (st % 4) == 0 &&
+                ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)out)) & 15) == 0);
+  return sea_attention_fwd_f16x2(q, k, v, sb, sh, st, B, H, T, scale, amax_ws, out, lse, (hipStream_t)stream);
+}
+
 // SEA_ATTN_TERMS (forward) / SEA_ATTN_TERMS_BWD: 3 or 2 = bf16 terms per operand on v_mfma_f32_32x32x16_bf16, 0 = the fp32
 // MFMA kernels of this file.  Defaults: 3 (= the fp32 operands exactly) forward AND backward (round 4: the evaluation is
 // fp32-equivalent end to end; 2 backward was round 3's default: the attack consumes only the sign of the input gradient).
@@ -374,18 +386,30 @@ static inline int attn_terms(bool backward) {   // looked up per call (two launc
   return (t == 2 || t == 3) ? t : 0;
 }
 
-// q/k/v: element (b,h,t,d) at ptr + b*sb + h*sh + t*st + d (floats), d contiguous, head dim 64, 16-byte aligned rows.
-extern "C" int sea_attention_fwd(const float* q, const float* k, const float* v, int64_t sb, int64_t sh, int64_t st, int B, int H,
-                                 int T, int D, float scale, float* out, float* lse, void* stream) {
+static int attention_fwd_impl(const float* q, const float* k, const float* v, int64_t sb, int64_t sh, int64_t st, int B, int H,
+                              int T, int D, float scale, float* out, float* lse, int terms, void* stream) {
   SEA_CHECK_ARG(q && k && v && out && lse && B > 0 && H > 0 && T > 0 && D == kD);
   SEA_CHECK_ARG((sb % 4) == 0 && (sh % 4) == 0 && (st % 4) == 0 &&
                 ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)out)) & 15) == 0);
-  if (const int terms = attn_terms(false))
+  if (terms)
     return sea_attention_fwd_bf16(q, k, v, sb, sh, st, B, H, T, scale, out, lse, terms, (hipStream_t)stream);
   AttnPtrs p{q, k, v, sb, sh, st};
   dim3 grid((T + 127) / 128, H, B), block(256);
   hipLaunchKernelGGL(attn_fwd_kernel, grid, block, 0, (hipStream_t)stream, p, T, H, scale, out, lse);
   SEA_RETURN_LAST();
+}
+
+// q/k/v: element (b,h,t,d) at ptr + b*sb + h*sh + t*st + d (floats), d contiguous, head dim 64, 16-byte aligned rows.
+extern "C" int sea_attention_fwd(const float* q, const float* k, const float* v, int64_t sb, int64_t sh, int64_t st, int B, int H,
+                                 int T, int D, float scale, float* out, float* lse, void* stream) {
+  return attention_fwd_impl(q, k, v, sb, sh, st, B, H, T, D, scale, out, lse, attn_terms(false), stream);
+}
+
+// same, with the number of bf16 terms of the products chosen by the caller (3, 2, or 0 = fp32 MFMA kernels)
+extern "C" int sea_attention_fwd_terms(const float* q, const float* k, const float* v, int64_t sb, int64_t sh, int64_t st, int B,
+                                       int H, int T, int D, float scale, float* out, float* lse, int terms, void* stream) {
+  SEA_CHECK_ARG(terms == 0 || terms == 2 || terms == 3);
+  return attention_fwd_impl(q, k, v, sb, sh, st, B, H, T, D, scale, out, lse, terms, stream);
 }
 
 static int attention_bwd_impl(const float* q, const float* k, const float* v, int64_t sb, int64_t sh, int64_t st, int B, int H,

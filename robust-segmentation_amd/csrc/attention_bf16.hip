@@ -569,7 +569,8 @@ __global__ __launch_bounds__(256) void attn_amax_bh_kernel(AttnPtrsB p, int T, i
                                                            uint32_t* __restrict__ out) {
   const int b = blockIdx.y, h = blockIdx.x;
   const float* src[4] = {p.q + (int64_t)b * p.sb + (int64_t)h * p.sh, p.k + (int64_t)b * p.sb + (int64_t)h * p.sh,
-                         p.v + (int64_t)b * p.sb + (int64_t)h * p.sh, go + ((int64_t)b * T) * (H * kD) + h * kD};
+                         p.v + (int64_t)b * p.sb + (int64_t)h * p.sh,
+                         go ? go + ((int64_t)b * T) * (H * kD) + h * kD : p.v + (int64_t)b * p.sb + (int64_t)h * p.sh};   // (forward: no dO)
   const int64_t stride[4] = {p.st, p.st, p.st, (int64_t)H * kD};
   uint32_t m[4] = {0, 0, 0, 0};
   const int d4 = threadIdx.x & 15;
@@ -601,6 +602,89 @@ __global__ __launch_bounds__(256) void attn_amax_bh_kernel(AttnPtrsB p, int T, i
     for (int i = 1; i < 4; ++i) r = part[w][i] > r ? part[w][i] : r;
     out[((int64_t)b * H + h) * 4 + w] = r;
   }
+}
+
+// ---- forward, fp16 x 2: the loop of attn_fwd_bf16_kernel with 22-bit operands in three products per pair ---------------------
+__global__ __launch_bounds__(256, 2) void attn_fwd_f16_kernel(AttnPtrsB p, int T, int H, float scale, const uint32_t* __restrict__ amax_bh,
+                                                              float* __restrict__ out, float* __restrict__ lse) {
+  __shared__ __attribute__((aligned(16))) char k_rm[2 * kImg];
+  __shared__ __attribute__((aligned(16))) char v_tr[2 * kImg];
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+  const int q_row = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const bool q_ok = q_row < T;
+  const bool wave_rows = blockIdx.x * 128 + wave * 32 < T;
+  const float* qb = p.q + (int64_t)b * p.sb + (int64_t)h * p.sh;
+  const float* kb = p.k + (int64_t)b * p.sb + (int64_t)h * p.sh;
+  const float* vb = p.v + (int64_t)b * p.sb + (int64_t)h * p.sh;
+  const uint32_t* aw = amax_bh + ((int64_t)b * H + h) * 4;
+  float sK, invK, sV, invV;
+  attn_pow2_scale(aw[1], sK, invK);
+  attn_pow2_scale(aw[2], sV, invV);
+  RowFrag<2> qf;  // Q[q_row][.] * scale * log2(e): scores come out in the log2 domain
+  float inv_q, amax_q;
+  load_row_frag_f16(qb, p.st, q_ok ? q_row : T - 1, half, scale * kLog2e, qf, inv_q, amax_q);
+  const float c_s = invK * inv_q;
+  const float s_p = 16384.f;                                           // P = exp2(s - max) <= 1
+  f32x16 o0 = zero16(), o1 = zero16();
+  float m_run = -INFINITY, l_run = 0.f;
+  const int n_tiles = (T + kTile - 1) / kTile;
+  f32x4 kr[4], vr[4];
+  load_tile_regs(kb, p.st, 0, T, kr);
+  load_tile_regs(vb, p.st, 0, T, vr);
+  for (int j = 0; j < n_tiles; ++j) {
+    __syncthreads();
+    stage_tile_f16<true, false>(k_rm, nullptr, kr, sK);
+    stage_tile_f16<false, true>(nullptr, v_tr, vr, sV);
+    __syncthreads();
+    if (j + 1 < n_tiles) {
+      load_tile_regs(kb, p.st, (j + 1) * kTile, T, kr);
+      load_tile_regs(vb, p.st, (j + 1) * kTile, T, vr);
+    }
+    if (!wave_rows) continue;
+    f32x16 s0 = rm_times_frag_f16(k_rm, 0, lane, qf, zero16());
+    f32x16 s1 = rm_times_frag_f16(k_rm, 1, lane, qf, zero16());
+    const int key0 = j * kTile;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      s0[t] *= c_s;
+      s1[t] *= c_s;
+    }
+    if (key0 + kTile > T) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        if (key0 + acc_row(t, half) >= T) s0[t] = -INFINITY;
+        if (key0 + 32 + acc_row(t, half) >= T) s1[t] = -INFINITY;
+      }
+    }
+    float m_t = s0[0];
+#pragma unroll
+    for (int t = 1; t < 16; ++t) m_t = fmaxf(m_t, s0[t]);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) m_t = fmaxf(m_t, s1[t]);
+    m_t = fmaxf(m_t, __shfl_xor(m_t, 32, 64));
+    const float m_new = fmaxf(m_run, m_t);
+    const float alpha = fast_exp2(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      s0[t] = fast_exp2(s0[t] - m_new);
+      s1[t] = fast_exp2(s1[t] - m_new);
+      psum += s0[t] + s1[t];
+    }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      o0[t] *= alpha;
+      o1[t] *= alpha;
+    }
+    tr_times_acc_f16(v_tr, 0, lane, s0, s_p, o0, o1);
+    tr_times_acc_f16(v_tr, 1, lane, s1, s_p, o0, o1);
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  store_rows_t(out + ((int64_t)b * T) * (H * kD) + h * kD, (int64_t)H * kD, q_row, q_ok, lane, o0, o1, invV * (1.f / 16384.f) / l_tot);
+  if (q_ok && half == 0) lse[((int64_t)b * H + h) * T + q_row] = (m_run + log2f(l_tot)) * kLn2;
 }
 
 // ---- dQ, fp16 x 2 ------------------------------------------------------------------------------------------------------
@@ -803,5 +887,15 @@ int sea_attention_bwd_f16x2(const float* q, const float* k, const float* v, int6
   hipLaunchKernelGGL(attn_dq_f16_kernel, grid, block, lds_dq, stream, p, T, H, scale, grad_out, lse, delta, amax_ws, dq, gsb, gsh, gst);
   hipLaunchKernelGGL(attn_dkv_f16_kernel, grid, block, lds_dkv, stream, p, T, H, scale, grad_out, lse, delta, amax_ws, dk, dv, gsb, gsh,
                      gst);
+  return (int)hipGetLastError();
+}
+
+// fp16 x 2 forward: amax_ws = 4 B H device words of scratch (filled here)
+int sea_attention_fwd_f16x2(const float* q, const float* k, const float* v, int64_t sb, int64_t sh, int64_t st, int B, int H, int T,
+                            float scale, uint32_t* amax_ws, float* out, float* lse, hipStream_t stream) {
+  AttnPtrsB p{q, k, v, sb, sh, st};
+  dim3 grid((T + 127) / 128, H, B), block(256);
+  hipLaunchKernelGGL(attn_amax_bh_kernel, dim3(H, B), block, 0, stream, p, T, H, (const float*)nullptr, amax_ws);
+  hipLaunchKernelGGL(attn_fwd_f16_kernel, grid, block, 0, stream, p, T, H, scale, amax_ws, out, lse);
   return (int)hipGetLastError();
 }

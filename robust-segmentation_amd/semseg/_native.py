@@ -75,6 +75,8 @@ _SIGS = {
                                _i64, _i64, _i64, _vp]),
     "sea_attention_bwd_terms": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _i64, _i64, _i64, _i, _vp]),
+    "sea_attention_fwd_terms": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp]),
+    "sea_attention_fwd_f16": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "sea_attention_bwd_f16": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                    _i64, _i64, _i64, _vp]),
     "sea_absmax_bits": (_i, [_vp, _i64, _i, _i, _i, _i64, _i, _vp, _vp]),
@@ -653,8 +655,9 @@ def unpatch2x2(rows, B, H, W):
 
 
 # ------------------------------------------------------------------------------------------------ M7
-def attention_qkv(qkv, scale: float):
-    """softmax(q k^T * scale) v for a packed (B,T,3,H,64) fp32 qkv tensor; returns (out (B,T,H*64), lse (B,H,T))."""
+def attention_qkv(qkv, scale: float, terms=None):
+    """softmax(q k^T * scale) v for a packed (B,T,3,H,64) fp32 qkv tensor; returns (out (B,T,H*64), lse (B,H,T)).
+    ``terms``: arithmetic of the products (22 = fp16 x 2, 3 / 2 = bf16 terms, 0 = fp32 MFMA); None = ``attn_terms_fwd()``."""
     _dev(qkv)
     qkv = _f32c(qkv)
     B, T, three, H, D = qkv.shape
@@ -663,8 +666,14 @@ def attention_qkv(qkv, scale: float):
     out = torch.empty(B, T, H * D, dtype=torch.float32, device=qkv.device)
     lse = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
     p = qkv.data_ptr()
-    _check(lib().sea_attention_fwd(p, p + 4 * H * D, p + 8 * H * D, T * 3 * H * D, D, 3 * H * D, B, H, T, D, float(scale),
-                                   _p(out), _p(lse), _stream()), "sea_attention_fwd")
+    terms = attn_terms_fwd() if terms is None else int(terms)
+    if terms == 22:
+        ws = torch.empty(4 * B * H, dtype=torch.int32, device=qkv.device)
+        _check(lib().sea_attention_fwd_f16(p, p + 4 * H * D, p + 8 * H * D, T * 3 * H * D, D, 3 * H * D, B, H, T, D, float(scale),
+                                           _p(ws), _p(out), _p(lse), _stream()), "sea_attention_fwd_f16")
+        return out, lse
+    _check(lib().sea_attention_fwd_terms(p, p + 4 * H * D, p + 8 * H * D, T * 3 * H * D, D, 3 * H * D, B, H, T, D, float(scale),
+                                         _p(out), _p(lse), terms, _stream()), "sea_attention_fwd_terms")
     return out, lse
 
 
@@ -679,10 +688,13 @@ def attn_terms_bwd() -> int:
     return t if t in (0, 2, 3, 22) else ATTN_TERMS_BWD_DEFAULT
 
 
+ATTN_TERMS_FWD_DEFAULT = 22
+
+
 def attn_terms_fwd() -> int:
-    """forward products (read by the library per call): env SEA_ATTN_TERMS or 3 bf16 terms per operand; 0 = fp32 MFMA"""
-    t = int(os.environ.get("SEA_ATTN_TERMS", 3))
-    return t if t in (2, 3) else 0
+    """forward products: env SEA_ATTN_TERMS (per call) or 22 = fp16 x 2; 3 / 2 = bf16 terms per operand; 0 = fp32 MFMA"""
+    t = int(os.environ.get("SEA_ATTN_TERMS", ATTN_TERMS_FWD_DEFAULT))
+    return t if t in (0, 2, 3, 22) else ATTN_TERMS_FWD_DEFAULT
 
 
 def attention_qkv_backward(qkv, out, lse, grad_out, scale: float, terms=None):

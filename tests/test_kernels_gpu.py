@@ -1070,12 +1070,12 @@ def test_counts_full_size_ade(N):
 # ------------------------------------------------------------------------------------------------ M7 attention
 @pytest.mark.parametrize("case", [(2, 6, 1025, "ViT-S/16 encoder, 512x512"), (1, 6, 1175, "mask transformer, 1024 patches + 151 classes"),
                                   (3, 2, 64, "one tile"), (1, 1, 33, "ragged"), (2, 3, 130, "two blocks, ragged")])
-@pytest.mark.parametrize("terms", [(3, 22), (3, 2), (3, 3), (0, 0)])
+@pytest.mark.parametrize("terms", [(22, 22), (3, 22), (3, 2), (3, 3), (0, 0)])
 def test_fp32_mfma_attention_forward_and_backward(N, case, terms):
     """softmax(q k^T * scale) v as written in the reference (vit_encoder.py:106-127), explicit fp32 (and an fp64 check).
     terms = (forward, backward) arithmetic of M7b (csrc/attention_bf16.hip): bf16 terms per operand, 22 = fp16 x 2; (0, 0) =
-    the fp32 MFMA kernels of M7.  Shipped: (3, 22): forward and log-sum-exp at fp32 level, input gradient with 22-bit
-    operands (fp32-level: the strict bound); (3, 2) is round 3's 16-bit gradient."""
+    the fp32 MFMA kernels of M7.  Shipped: (22, 22): forward, log-sum-exp and input gradient with 22-bit operands (fp32-level:
+    the strict bounds); (3, 2) is round 3's 16-bit gradient."""
     import os
     B, H, T, _ = case
     os.environ["SEA_ATTN_TERMS"], os.environ["SEA_ATTN_TERMS_BWD"] = str(terms[0]), str(terms[1])

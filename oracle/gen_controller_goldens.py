@@ -171,6 +171,61 @@ def main():
             net_seed=np.int64(C + 40 + seed), min_gap=np.float64(gap), x_adv=xa, acc=acc)))
 
 
+def near_tie(loss="mask-ce-bal", n_iter=90, max_gap=1e-5, seeds=400):
+    """g13_ctrl_neartie_*: the OPPOSITE selection of main(): the first seed whose reference run makes a decisive loss
+    comparison within `max_gap` (relative) of a tie -- closer than the device kernels' own loss error budget of 2e-5 that the
+    other fixtures keep clear of.  The GPU test asserts what can be asserted there: the product reproduces the reference's
+    iterates through the near-tie, or leaves them at an evaluation AFTER it and nowhere before."""
+    os.chdir(REF)
+    torch.set_num_threads(2)
+    import semseg.attacker as A
+    from autoattack.other_utils import Logger
+    from semseg.utils.utils import VOC_WTS
+    from oracle.tiny_models import PointwiseNet, make_labels
+    logger, C, w = Logger(None), 21, torch.tensor(VOC_WTS)
+    for seed in range(seeds):
+        net = PointwiseNet(C, seed=C + 100 + seed)
+        g = torch.Generator().manual_seed(17000 + 31 * seed + n_iter)
+        x = torch.rand(3, 3, 16, 16, generator=g)
+        y = make_labels(net, x, ignore_frac=0.05, flip_frac=0.1, seed=C + seed)
+        eps = 8.0 / 255
+        x_init = (x + eps * (2 * torch.rand(x.shape, generator=g) - 1)).clamp(0, 1)
+        mask_bg = (y != -1).float()
+
+        def stats(logits):
+            with torch.no_grad():
+                li = A.pixel_to_img_loss(A.criterion_dict[loss](logits, y, w), mask_bg)
+                ce = A.pixel_to_img_loss(A.criterion_dict["ce-avg"](logits, y), mask_bg)
+                n_correct = (logits.max(1)[1] == y).flatten(1).sum(1)
+            return dict(li=li.clone(), ce=ce.clone(), n_correct=n_correct)
+
+        rec = Recorder(net, stats).eval()
+        with contextlib.redirect_stdout(io.StringIO()):
+            xb, acc, lb, xba = A.apgd_train(rec, x, y, "Linf", eps, n_iter=n_iter, use_rs=False, loss=loss, track_loss="ce-avg",
+                                            logger=logger, x_init=x_init, num_classes=C, weights=w, early_stop=True)
+        if len(rec.evals) != n_iter + 1:
+            continue
+        gap = smallest_gaps(torch.stack([e["ce"] for e in rec.evals]), [n_iter])
+        if gap < max_gap:
+            break
+    else:
+        raise SystemExit(f"no seed with a comparison within {max_gap:g} of a tie in {seeds} tries")
+    out = dict(x=x, y=y, w=w, x_init=x_init, eps=np.float64(eps), n_iter=np.int64(n_iter), net_seed=np.int64(C + 100 + seed),
+               min_gap=np.float64(gap), x_best=xb, acc=acc, loss_best=lb, x_best_adv=xba, n_evals=np.int64(len(rec.evals)))
+    for k in ("chk", "li", "ce", "n_correct"):
+        out[k] = torch.stack([e[k] for e in rec.evals])
+    out["has_grad"] = np.array([e["g"] is not None for e in rec.evals])
+    for j, e in enumerate(rec.evals):
+        if e["g"] is not None:
+            gg = e["g"].flatten()
+            out[f"e{j}_neg"] = np.packbits((gg < 0).numpy())
+            out[f"e{j}_zero"] = np.packbits((gg == 0).numpy())
+    name = f"g13_ctrl_neartie_{loss}_{n_iter}"
+    np.savez_compressed(os.path.join(OUT, name + ".npz"),
+                        **{k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in out.items()})
+    print("wrote", name, f"seed {seed}: smallest relative gap of a decisive loss comparison {gap:.2e}", flush=True)
+
+
 def real_model(n_iter=40, loss="mask-ce-bal", threads=2):
     """g13_ctrl_real_upernet_t_*: the reference's apgd_largereps on the REAL UperNet-ConvNeXt-T at 512 x 512 with n_iter = 40
     (stages 12 / 12 / 16: long enough for the product's HIP-graph replay in every stage), eps 4/255.  Stored: checksums of
@@ -229,7 +284,11 @@ def real_model(n_iter=40, loss="mask-ce-bal", threads=2):
 
 
 if __name__ == "__main__":
-    if "--real" in sys.argv:
+    if "--near-tie" in sys.argv:
+        # python oracle/gen_controller_goldens.py --near-tie [loss [n_iter]]
+        rest = [a for a in sys.argv[1:] if a != "--near-tie"]
+        near_tie(loss=rest[0] if rest else "mask-ce-bal", n_iter=int(rest[1]) if len(rest) > 1 else 90)
+    elif "--real" in sys.argv:
         # python oracle/gen_controller_goldens.py --real [loss [n_iter]]
         rest = [a for a in sys.argv[1:] if a != "--real"]
         real_model(loss=rest[0] if rest else "mask-ce-bal", n_iter=int(rest[1]) if len(rest) > 1 else 40)

@@ -56,7 +56,7 @@ def timed(ko, reps=20):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-NAMES = {1: "no C stores", 2: "no A loads", 4: "no W loads", 8: "no MFMA", 16: "no LDS writes", 64: "nt C stores"}
+NAMES = {1: "no C stores", 2: "no A loads", 4: "no W loads", 8: "no MFMA", 16: "no LDS writes", 64: "nt C stores", 128: "no operand split (VALU)"}
 print(f"G={G} M={M} K={K} N={Nn}  fp16x2 ping-pong kernel, 20 launches back to back, two rounds")
 KOS = [int(a[5:]) for a in sys.argv if a.startswith('--ko=')] or [0, 64, 1, 2, 4, 6, 8, 72, 16, 7, 9, 24, 14, 15, 25, 31]
 for ko in KOS:

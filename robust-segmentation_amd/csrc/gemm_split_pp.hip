@@ -137,6 +137,13 @@ __global__ __launch_bounds__(256, 2) void gemm_split_pp_kernel(const GemmSplitAr
   f32x4 sv;
   uint32_t hi_a, hi_b;   // (two scalars, NOT a u32x2: hipcc 7.2 folds bit_cast<f16x2>(v[1]) of a 2-vector to v[0]'s halves)
   auto unit_a = [&](Tile& R, int i, int part, char* stage) __attribute__((always_inline)) {
+    if constexpr ((KO & 128) != 0) {   // timing only: no operand split (what a producer that writes fp16 term planes would leave)
+      if (part == 2) {
+        *(u32x2*)(stage + a_wr[i]) = u32x2{__float_as_uint(R.a[i][0]), __float_as_uint(R.a[i][1])};
+        if constexpr (TERMS == 2) *(u32x2*)(stage + GS_IMG + a_wr[i]) = u32x2{__float_as_uint(R.a[i][2]), __float_as_uint(R.a[i][3])};
+      }
+      return;
+    }
     if (part == 0) {
       f32x4 v = R.a[i];
       if constexpr (PRO == 1) {
@@ -389,6 +396,8 @@ extern "C" int sea_gemm_pp_knockout(const float* A, int64_t lda, const void* Wp,
     case 25: ko_launch<25>(p, st); break;
     case 64: ko_launch<64>(p, st); break;   // (64: non-temporal C stores)
     case 72: ko_launch<72>(p, st); break;
+    case 128: ko_launch<128>(p, st); break;   // (128: no VALU split of A)
+    case 129: ko_launch<129>(p, st); break;
     default: return 1;
   }
   return (int)hipGetLastError();

@@ -584,10 +584,16 @@ def wino_conv3x3_cl(x, U, m: int, bias=None, scale=None, relu: bool = False, gat
         off += t.shape[1]
     if use_split:
         # M8: the (A*A) Winograd-domain products on the bf16 matrix cores (operands split into bf16 terms, fp32 accumulate)
-        packed = U.__dict__.setdefault("_sea_packed", {})   # U is the cached, frozen filter image: packed once per term count
-        Up = packed.get(gemm_terms)
-        if Up is None:
-            Up = packed[gemm_terms] = gemm_split_pack(U, trans=True, terms=gemm_terms)
+        # U is the cached, frozen filter image: packed once per term count and per CONTENT (a caller that refreshes U in place
+        # -- fixed addresses for captured graphs -- bumps its version: the packed image is then refreshed in place too)
+        packed = U.__dict__.setdefault("_sea_packed", {})
+        Up, ver = packed.get(gemm_terms, (None, None))
+        if Up is None or ver != U._version:
+            fresh = gemm_split_pack(U, trans=True, terms=gemm_terms)
+            if Up is None or not Up.refresh_from(fresh):
+                Up = fresh
+                CACHE_EPOCH[0] += 1
+            packed[gemm_terms] = (Up, U._version)
         Mx = gemm_split(V, Up, amax=v_amax, amax_rows=1 if v_amax is not None else 0, groups=B)
     else:
         with torch.autocast("cuda", enabled=False):
@@ -739,6 +745,11 @@ def worst_miou_greedy(ints: torch.Tensor, unions: torch.Tensor, mt_state, n_roun
 
 
 # ------------------------------------------------------------------------------------------------ M8
+# Bumped whenever a weight-derived cache tensor is (re)created at a NEW device address (first use, or a shape change): a
+# caller that captured a HIP graph over the model compares it with the value it saw at capture time.
+CACHE_EPOCH = [0]
+
+
 class PackedWeight:
     """Frozen weights W (N x K) pre-split into `terms` bf16 images in the tile order of sea_gemm_split
     (optionally a batch of them, e.g. the (m+2)^2 Winograd-domain filters)."""
@@ -749,13 +760,29 @@ class PackedWeight:
         self.src = src          # (W, trans) of a single matrix: K slices are packed from it on demand (split-K)
         self.slices = {}
 
+    def _slices_of(self, S):
+        W, trans = self.src
+        Ws = W.view(S, self.K // S, self.N) if trans else W.view(self.N, S, self.K // S).permute(1, 0, 2)
+        return gemm_split_pack(Ws, trans=trans, terms=self.terms)
+
     def k_slices(self, S):
         """this weight as a batch of S packed (N x K/S) matrices, one per K slice"""
         if S not in self.slices:
-            W, trans = self.src
-            Ws = W.view(S, self.K // S, self.N) if trans else W.view(self.N, S, self.K // S).permute(1, 0, 2)
-            self.slices[S] = gemm_split_pack(Ws, trans=trans, terms=self.terms)
+            self.slices[S] = self._slices_of(S)
         return self.slices[S]
+
+    def refresh_from(self, new) -> bool:
+        """take the contents of ``new`` (the same weight, packed again after it changed) INTO this object's buffers: the
+        packed image -- and every K-slice image derived from it -- keeps its device address, which is what lets a captured
+        HIP graph outlive a weight update (PIR-AT: the weights change every outer step).  False if the shapes differ."""
+        if (self.data.shape != new.data.shape or (self.N, self.K, self.terms, self.batch) != (new.N, new.K, new.terms, new.batch)
+                or (self.src is None) != (new.src is None)):
+            return False
+        self.data.copy_(new.data)
+        self.src = new.src
+        for S, sl in self.slices.items():
+            sl.data.copy_(self._slices_of(S).data)
+        return True
 
 
 def gemm_split_pack(W, trans: bool = False, terms: int = 3) -> PackedWeight:

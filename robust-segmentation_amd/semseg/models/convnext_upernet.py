@@ -223,6 +223,31 @@ def _tkey(*ts):
     return tuple((id(t), t.data_ptr(), t._version, t.device.index) for t in ts if t is not None)
 
 
+def _stable(old, new):
+    """Store a re-derived cache value at the OLD value's device address when shapes allow: a tensor is copied into the
+    old tensor (same address, in-place version bumped, so caches derived from IT notice), a packed weight into the old packed
+    buffers, lists / tuples element-wise.  A captured HIP graph over the model (semseg/val.py: the inner PGD of PIR-AT, whose
+    weights change every outer step) then stays valid after a weight update as long as one eager pass has refreshed the
+    caches; `_native.CACHE_EPOCH` counts the values that could NOT keep their address."""
+    from .. import _native as N
+    if isinstance(new, N.PackedWeight):
+        if isinstance(old, N.PackedWeight) and old.refresh_from(new):
+            return old
+        N.CACHE_EPOCH[0] += 1
+        return new
+    if isinstance(new, torch.Tensor):
+        if (isinstance(old, torch.Tensor) and old is not new and old.shape == new.shape and old.dtype == new.dtype
+                and old.device == new.device and old.stride() == new.stride()):
+            old.copy_(new)
+            return old
+        N.CACHE_EPOCH[0] += 1
+        return new
+    if isinstance(new, (list, tuple)):
+        olds = old if isinstance(old, (list, tuple)) and len(old) == len(new) else [None] * len(new)
+        return type(new)(_stable(o, n) for o, n in zip(olds, new))
+    return new
+
+
 # M8 (csrc/gemm_split.hip): the frozen-weight GEMMs of the attacked model on the bf16 matrix cores by operand splitting.
 #   3: every fp32 operand as three bf16 terms, six MFMA products -> fp32-level accuracy
 #   2: two terms, three products (16 significant bits per operand; 64x finer than the TF32 convolutions the reference's
@@ -291,7 +316,7 @@ def _packed(w, cache, name, trans, terms):
     key = (_tkey(w), trans)
     if cache.get(name + "_key") != key:
         with torch.no_grad():
-            cache[name] = N.gemm_split_pack(w.detach(), trans=trans, terms=terms)
+            cache[name] = _stable(cache.get(name), N.gemm_split_pack(w.detach(), trans=trans, terms=terms))
         cache[name + "_key"] = key
     return cache[name]
 
@@ -323,7 +348,7 @@ def _ln_bound_word(norm, cache):
     if cache.get("ln_bound_key") != key:
         with torch.no_grad():
             bnd = norm.weight.numel() ** 0.5 * norm.weight.abs().max() + norm.bias.abs().max()
-            cache.update(ln_bound_key=key, ln_bound=bnd.float().reshape(1).contiguous().view(torch.int32))
+            cache.update(ln_bound_key=key, ln_bound=_stable(cache.get("ln_bound"), bnd.float().reshape(1).contiguous().view(torch.int32)))
     return cache["ln_bound"]
 
 
@@ -332,7 +357,7 @@ def _linear_bound_word(in_word, w, b, cache):
     (``in_word``: float bits of that bound), hence of GELU / ReLU of it and of any convex combination of its rows (attention).
     The fp16 x 2 scale of the NEXT GEMM without a pass over the activations and without any dependence on the batch.
     Cached until the weights change."""
-    key = _tkey(w, b)
+    key = (_tkey(w, b), in_word._version)      # (the input word may be refreshed in place: its version is part of the key)
     # (the input word is compared by identity and kept referenced: a re-derived word can then never reuse its address)
     if cache.get("lin_bound_key") != key or cache.get("lin_bound_in") is not in_word:
         with torch.no_grad():
@@ -340,7 +365,7 @@ def _linear_bound_word(in_word, w, b, cache):
             if b is not None:
                 bnd = bnd + b.abs()
             cache.update(lin_bound_key=key, lin_bound_in=in_word,
-                         lin_bound=bnd.max().float().reshape(1).contiguous().view(torch.int32))
+                         lin_bound=_stable(cache.get("lin_bound"), bnd.max().float().reshape(1).contiguous().view(torch.int32)))
     return cache["lin_bound"]
 
 
@@ -352,7 +377,7 @@ def _l1_bound(w, cache, dim, factor=1.0):
     key = (_tkey(w), dim, factor)
     if cache.get("l1_key") != key:
         with torch.no_grad():
-            cache.update(l1_key=key, l1=(w.detach().abs().sum(dim).max() * (factor * (1.0 + 1e-6))).float().reshape(1))
+            cache.update(l1_key=key, l1=_stable(cache.get("l1"), (w.detach().abs().sum(dim).max() * (factor * (1.0 + 1e-6))).float().reshape(1)))
     return cache["l1"]
 
 
@@ -492,7 +517,7 @@ def _taps_major(conv: nn.Conv2d):
     key = _tkey(w)
     cached = getattr(conv, "_sea_wt", None)
     if cached is None or cached[0] != key:
-        cached = (key, w.detach().reshape(w.shape[0], 49).t().contiguous())
+        cached = (key, _stable(None if cached is None else cached[1], w.detach().reshape(w.shape[0], 49).t().contiguous()))
         conv._sea_wt = cached
     return cached[1]
 
@@ -616,7 +641,8 @@ class Block(nn.Module):
                 cache = self.__dict__.setdefault("_fold_cache", {})
                 if cache.get("key") != key:
                     with torch.no_grad():
-                        cache.update(key=key, w=(w2 * g[:, None]).contiguous(), b=None if b2 is None else b2 * g)
+                        cache.update(key=key, w=_stable(cache.get("w"), (w2 * g[:, None]).contiguous()),
+                                     b=None if b2 is None else _stable(cache.get("b"), b2 * g))
                 yn = self.norm(y)
                 if isinstance(self.act, nn.GELU) and self.act.approximate == "none" and _mlp_fusable(
                         yn, self.pwconv1.weight, self.pwconv1.bias, cache["w"], cache["b"]):
@@ -655,7 +681,7 @@ class _PatchConv2x2(torch.autograd.Function):
         B, C, H, W = x.shape
         key = _tkey(weight)
         if cache.get("key") != key:
-            cache.update(key=key, w=weight.detach().permute(0, 2, 3, 1).reshape(weight.shape[0], 4 * C).contiguous())
+            cache.update(key=key, w=_stable(cache.get("w"), weight.detach().permute(0, 2, 3, 1).reshape(weight.shape[0], 4 * C).contiguous()))
         wr = cache["w"]                                                        # (Cout, (di, dj, c))
         from .. import _native as N
         xn = x.permute(0, 2, 3, 1)
@@ -766,7 +792,8 @@ class _WinoConv3x3(torch.autograd.Function):
         from .. import _native as N
         key = (_tkey(weight), m)
         if cache.get("key") != key:
-            cache.update(key=key, fwd=N.wino_filter(weight.contiguous(), m, False), bwd=None)
+            # (the backward image is refreshed lazily, in place: `bwd_key` says which weights it was derived from)
+            cache.update(key=key, fwd=_stable(cache.get("fwd"), N.wino_filter(weight.contiguous(), m, False)))
         ctx.cache, ctx.m, ctx.weight, ctx.relu, ctx.terms = cache, m, weight, relu, _terms()
         y = N.wino_conv3x3_cl(_dense_cl(x), cache["fwd"], m, bias=shift, scale=scale, relu=relu, gemm_terms=ctx.terms)
         if relu:
@@ -778,8 +805,8 @@ class _WinoConv3x3(torch.autograd.Function):
     def backward(ctx, gy):
         from .. import _native as N
         cache = ctx.cache
-        if cache.get("bwd") is None:
-            cache["bwd"] = N.wino_filter(ctx.weight.contiguous(), ctx.m, True)
+        if cache.get("bwd") is None or cache.get("bwd_key") != cache.get("key"):
+            cache.update(bwd=_stable(cache.get("bwd"), N.wino_filter(ctx.weight.contiguous(), ctx.m, True)), bwd_key=cache.get("key"))
         gate, gscale = ctx.saved_tensors if ctx.relu else (None, None)
         g = gy if N.cl_pixel_stride(gy) is not None else gy.contiguous(memory_format=_CL)  # slices read in place
         gx = N.wino_conv3x3_cl(g, cache["bwd"], ctx.m, gate=gate, gate_scale=gscale, gemm_terms=_bwd_terms(ctx.terms))
@@ -800,7 +827,8 @@ def _folded_bn(bn, conv_bias, cache):
                 shift = shift + bn.bias
             if conv_bias is not None:
                 shift = shift + scale * conv_bias
-        cache.update(bn_key=key, scale=scale.float().contiguous(), shift=shift.float().contiguous())
+        cache.update(bn_key=key, scale=_stable(cache.get("scale"), scale.float().contiguous()),
+                     shift=_stable(cache.get("shift"), shift.float().contiguous()))
     return cache["scale"], cache["shift"]
 
 
@@ -870,7 +898,7 @@ class ConvModule(nn.Module):
         key = (_tkey(w), cache["bn_key"])
         if cache.get("pw_key") != key:
             with torch.no_grad():
-                cache.update(pw_key=key, pw_w=(w.view(w.shape[0], -1) * scale[:, None]).contiguous())
+                cache.update(pw_key=key, pw_w=_stable(cache.get("pw_w"), (w.view(w.shape[0], -1) * scale[:, None]).contiguous()))
         B, _, H, W = x.shape
         # 2-D GEMM on the (pixels, Cin) view; ReLU in place on the GEMM's own output (an in-place op on a VIEW of it
         # would make autograd clone / copy whole tensors in CopySlices)
@@ -1054,9 +1082,11 @@ class _FpnBottleneck(torch.autograd.Function):
         key = (_tkey(weight), m, tuple(hi), tuple(chans))
         if cache.get("fpn_key") != key:
             w_hi = torch.cat([weight[:, offs[i]:offs[i] + chans[i]] for i in hi], 1).contiguous()
-            cache.update(fpn_key=key, fpn_fwd=N.wino_filter(w_hi, m, False), fpn_bwd=N.wino_filter(w_hi, m, True),
-                         fpn_lo=[weight[:, offs[i]:offs[i] + chans[i]].permute(2, 3, 0, 1).reshape(9 * Cout, chans[i])
-                                 .contiguous() for i in lo])  # rows (tap, cout): F.linear -> (B,h,w,9*Cout)
+            cache.update(fpn_key=key, fpn_fwd=_stable(cache.get("fpn_fwd"), N.wino_filter(w_hi, m, False)),
+                         fpn_bwd=_stable(cache.get("fpn_bwd"), N.wino_filter(w_hi, m, True)),
+                         fpn_lo=_stable(cache.get("fpn_lo"), [weight[:, offs[i]:offs[i] + chans[i]].permute(2, 3, 0, 1)
+                                                              .reshape(9 * Cout, chans[i]).contiguous() for i in lo]))
+            # rows of fpn_lo (tap, cout): F.linear -> (B,h,w,9*Cout)
         # the fine inputs are transformed side by side into the Winograd domain: no concatenation buffer
         xs = [_dense_cl(fs[i]) if tuple(fs[i].shape[2:]) == (H, W) else N.upsample_bilinear_cl(_dense_cl(fs[i]), (H, W))
               for i in hi]

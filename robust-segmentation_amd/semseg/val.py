@@ -8,6 +8,10 @@ no gradient all-reduce fires inside the inner loop.
 """
 from __future__ import annotations
 
+import os
+import sys
+import weakref
+
 import torch
 
 from . import _native as N
@@ -69,6 +73,48 @@ def _fwd_grad(model, x_in, y, los, scale, ws, out, dlogits):
     return g.contiguous(), r, logits.detach()
 
 
+# ---- HIP-graph replay of the inner PGD (round 5; opt-in: SEA_PGD_GRAPH=1) ----------------------------------------------------
+# PIR-AT runs this attack once per outer step on weights the optimizer has just changed.  A captured iteration used to be
+# impossible because every weight-derived cache (packed weights, folded BatchNorm, Winograd-domain filters, analytic bounds)
+# was re-created at a new address after each optimizer step.  Those caches now refresh IN PLACE
+# (models/convnext_upernet.py:_stable), so: iteration 0 of every attack runs eagerly -- which re-derives every cache the
+# forward and the backward touch, through the ordinary code path -- and iterations 1 .. n - 1 replay ONE captured graph
+# (forward, fused loss / gradient kernel, input-gradient backward, sign step) over persistent buffers.  The graph is valid for
+# one set of parameter objects / addresses and for one `_native.CACHE_EPOCH` (bumped whenever a cache value could NOT keep its
+# address); anything else captures again.  Bitwise the eager loop across weight updates, fp32 and bf16 (tests/test_attack_gpu.py).
+# MEASURED (BASELINE configs[3]: UperNet-ConvNeXt-S, B = 8, 512 x 512, bf16 autocast, 5 steps; devtools/pirat_host_vs_gpu.py,
+# profiles/r5_pirat_host_vs_gpu.log): the host time to enqueue the attack drops from 84-103 ms to 24-27 ms per outer step,
+# the attack's GPU time stays at 98-104 ms and the outer step at 194-197 ms -- at this size the eager loop was GPU-bound
+# with the host just keeping pace, so the replay buys host time (eight ranks on one host), not throughput.  Hence opt-in.
+PGD_GRAPH = os.environ.get("SEA_PGD_GRAPH", "0") == "1"
+PGD_GRAPH_MIN_ITER = 3
+_PGD_SLOTS = weakref.WeakKeyDictionary()     # model -> {key: _PgdSlot}
+
+
+class _PgdSlot:
+    def __init__(self, X, y):
+        self.X, self.delta, self.x_in = torch.empty_like(X), torch.empty_like(X), torch.empty_like(X)
+        self.y = torch.empty_like(y)
+        B, HW = X.shape[0], X.shape[-2] * X.shape[-1]
+        self.ws = N.loss_workspace(B, HW, X.device)
+        self.out = tuple(torch.empty(B, dtype=d, device=X.device) for d in (torch.float32, torch.float32, torch.int32))
+        self.dl = None
+        self.graph = self.logits = self.pin = None
+        self.epoch = self.wkey = None
+        self.warm = False          # one eager iteration has run on the capture stream (library state per stream)
+        self.failed = False
+
+
+def _param_key(model):
+    return hash(tuple((id(t), t.data_ptr()) for t in list(model.parameters()) + list(model.buffers())))
+
+
+def release_pgd_graphs(model=None):
+    """drop the captured inner-PGD graphs (and their activation pools) of ``model``, or of every model"""
+    for m in ([model] if model is not None else list(_PGD_SLOTS.keys())):
+        _PGD_SLOTS.pop(m, None)
+
+
 class Pgd_Attack_1:
     """Random-start PGD, model sees X+delta unclamped (val.py:181-218)."""
 
@@ -87,6 +133,11 @@ class Pgd_Attack_1:
         scale = 1.0 / (HW if self.per_image else B * HW)
         ws = N.loss_workspace(B, HW, X.device)
         out = tuple(torch.empty(B, dtype=d, device=X.device) for d in (torch.float32, torch.float32, torch.int32))
+        if (PGD_GRAPH and self.mode is not None and self.num_iter >= PGD_GRAPH_MIN_ITER and X.is_cuda
+                and isinstance(model, torch.nn.Module)):
+            res = self._adv_attack_graph(model, X, y, delta, scale)
+            if res is not None:
+                return res
         x_in = X + delta
         logits, dl = None, None
         for _ in range(self.num_iter):
@@ -96,6 +147,70 @@ class Pgd_Attack_1:
                             clamp_input=False)
         x_adv = (X + delta).clamp_(0.0, 1.0)
         return x_adv.detach(), logits, None
+
+    def _adv_attack_graph(self, model, X, y, delta, scale):
+        """iteration 0 eager (refreshes the weight-derived caches in place), the rest replayed from one captured graph; returns
+        None when this model / shape cannot be captured (the caller then runs the eager loop from the same start)"""
+        try:
+            slots = _PGD_SLOTS.setdefault(model, {})
+        except TypeError:
+            return None
+        ac = (torch.is_autocast_enabled(), torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else None)
+        key = (tuple(X.shape), tuple(y.shape), y.dtype, X.device.index, self.mode, self.per_image, float(self.alpha),
+               float(self.epsilon), ac)
+        sl = slots.get(key)
+        if sl is None:
+            sl = slots[key] = _PgdSlot(X, y)
+        if sl.failed:
+            return None
+        sl.X.copy_(X)
+        sl.y.copy_(y)
+        sl.delta.copy_(delta)
+        torch.add(sl.X, sl.delta, out=sl.x_in)
+        alpha, eps = float(self.alpha), float(self.epsilon)
+
+        def iteration():
+            g, r, logits = _fwd_grad(model, sl.x_in, sl.y, self.loss_fn, scale, sl.ws, sl.out, sl.dl)
+            sl.dl = r["dlogits"]
+            N.pgd_linf_step(sl.X, sl.delta, g, alpha, eps, delta_out=sl.delta, x_in_out=sl.x_in, clamp_input=False)
+            return logits
+
+        logits = iteration()                     # eager: every cache the forward and the backward use is current again
+        wkey = _param_key(model)
+        if sl.graph is not None and (sl.epoch != N.CACHE_EPOCH[0] or sl.wkey != wkey):
+            sl.graph = sl.logits = sl.pin = None      # some cache moved, or other parameter tensors: capture again
+        it = 1
+        cur = torch.cuda.current_stream()
+        gs = _A._capture_stream(X.device)
+        if sl.graph is None:
+            if not sl.warm:                      # per-stream library state must exist before a capture starts
+                gs.wait_stream(cur)
+                with torch.cuda.stream(gs):
+                    logits = iteration()
+                cur.wait_stream(gs)
+                sl.warm = True
+                it += 1
+            if it < self.num_iter:
+                graph = torch.cuda.CUDAGraph()
+                try:
+                    with torch.cuda.graph(graph, stream=gs):
+                        sl.logits = iteration()
+                except Exception as exc:         # a model that cannot be captured keeps the eager loop, from here on
+                    torch.cuda.set_stream(cur)
+                    torch.cuda.synchronize()
+                    sl.failed = True
+                    print(f"[sea] HIP-graph capture of the inner PGD failed ({type(exc).__name__}: "
+                          f"{str(exc).splitlines()[0][:160]}); continuing with the eager loop", file=sys.stderr)
+                    for _ in range(it, self.num_iter):
+                        logits = iteration()
+                    return (sl.X + sl.delta).clamp_(0.0, 1.0).detach(), logits, None
+                sl.graph, sl.epoch, sl.wkey = graph, N.CACHE_EPOCH[0], wkey
+                sl.pin = N.ksplit_workspace_pin(X.device)
+        for _ in range(it, self.num_iter):
+            sl.graph.replay()
+            logits = sl.logits
+        x_adv = (sl.X + sl.delta).clamp_(0.0, 1.0)
+        return x_adv.detach(), (logits.clone() if logits is not None else None), None
 
 
 class Pgd_Attack:

@@ -359,3 +359,45 @@ def test_one_captured_graph_pair_serves_every_stage_loss_and_batch(A):
     assert not torch.equal(cached[0][0], cached[1][0])
     A.release_graph_cache(net)
     assert net not in A._GRAPH_SLOTS
+
+
+@pytest.mark.parametrize("amp", [False, True])
+def test_inner_pgd_graph_survives_weight_updates_bitwise(amp):
+    """PIR-AT's inner PGD (semseg/val.py:Pgd_Attack_1, reference val.py:181-218 + tools/train_rob_seg.py:326-352): iteration 0
+    eager, the rest replayed from ONE captured graph, across optimizer-style in-place weight updates -- every weight-derived
+    cache refreshes in place, so the graph captured in the first outer step serves the later ones.  Bitwise the eager loop in
+    every outer step (fp32 and under bf16 autocast), and no second capture."""
+    from semseg import val as V
+    from semseg.models import UperNetForSemanticSegmentation
+    torch.manual_seed(0)
+    model = UperNetForSemanticSegmentation("ConvNeXt-T_CVST", 21, None).cuda().eval()
+    g = torch.Generator().manual_seed(3)
+    X = torch.rand(2, 3, 512, 512, generator=g).cuda()
+    y = torch.randint(0, 21, (2, 16, 16), generator=g).repeat_interleave(32, 1).repeat_interleave(32, 2).cuda()
+    atk = V.Pgd_Attack_1(epsilon=4 / 255, alpha=1e-2, num_iter=5, los="pgd")
+    V.release_pgd_graphs()
+    graphs = []
+    for outer in range(3):
+        delta0 = (torch.rand(X.shape, generator=g).cuda() * 2 - 1) * (4 / 255)
+        outs = {}
+        for mode in (True, False):
+            old, V.PGD_GRAPH = V.PGD_GRAPH, mode
+            try:
+                with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                    outs[mode] = atk.adv_attack(model, X, y, delta0=delta0)
+            finally:
+                V.PGD_GRAPH = old
+        assert torch.equal(outs[True][0], outs[False][0]), f"outer step {outer}: graph replay != eager loop"
+        assert torch.equal(outs[True][1].float(), outs[False][1].float())
+        assert (outs[True][0] - X).abs().max() <= 4 / 255 + 1e-6
+        (slot,) = V._PGD_SLOTS[model].values()
+        assert slot.graph is not None and not slot.failed
+        graphs.append(slot.graph)
+        with torch.no_grad():                       # what an optimizer step does: every parameter and BatchNorm buffer, in place
+            for p in model.parameters():
+                p.add_(torch.randn(p.shape, generator=torch.Generator(device="cuda").manual_seed(outer), device="cuda") * 1e-3 * p.abs().mean())
+            for b in model.buffers():
+                if b.dtype.is_floating_point:
+                    b.mul_(1.01)
+    assert graphs[0] is graphs[1] is graphs[2], "the inner PGD was captured again after a weight update"
+    V.release_pgd_graphs(model)

@@ -274,15 +274,13 @@ def _input_grad(logits, x_in, dlogits):
     return g if g.is_contiguous() else g.contiguous()
 
 
-# K2u (loss fused with the model's final bilinear upsample; needs `model.forward_lowres`).
-#   "auto": fuse only when the materialised full-resolution logits and their gradient would not fit comfortably
-#           (more than FUSE_UPSAMPLE_AUTO_BYTES together): K2u never materialises them (2.5 GB at B=8, C=151, 512^2).
-#           Measured on MI355X (B=8, 512x512, fp32, profiles/r2_final_bench.log ff.): since the power-of-two
-#           up-sampling kernels (M2) and the class-split K2 of round 2 the unfused path is the faster one everywhere:
-#           Segmenter ViT-S/16 x16, C=151: 22.4 ms/step unfused vs 23.2 ms fused (round 1: 32.6 vs 26.1);
-#           UperNet x4: C=21 equal, C=151 unfused faster.
-#   True / False force it.
-FUSE_UPSAMPLE = "auto"
+# K2u (loss fused with the model's final bilinear upsample; needs `model.forward_lowres`): a MEMORY-SAVING mode, not a fast path.
+# It never materialises the full-resolution logits and their gradient (2.5 GB at B=8, C=151, 512^2) but is 2 x slower than
+# up-sample + K2 + up-sample-backward on every BASELINE config (profiles/r3_cold_kernel_roofline.md), so since round 5 nothing
+# selects it by itself: SEA_FUSE_UPSAMPLE=1 (or fuse_upsample=True) forces it, SEA_FUSE_UPSAMPLE=auto fuses only when the
+# materialised tensors would exceed FUSE_UPSAMPLE_AUTO_BYTES, the default is the unfused path.
+_fu = os.environ.get("SEA_FUSE_UPSAMPLE", "0")
+FUSE_UPSAMPLE = "auto" if _fu == "auto" else (_fu == "1")
 FUSE_UPSAMPLE_AUTO_BYTES = 24 * 2 ** 30
 
 # HIP-graph replay of the middle iterations of an APGD run (see ApgdRun._capture).  SEA_HIP_GRAPH=0 disables it.

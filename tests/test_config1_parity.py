@@ -61,7 +61,7 @@ def test_config1_device_path_matches_reference(tile):
         _run_config1(A, g, model, x, y, w, noises)
     finally:
         M.WINOGRAD_TILE = old_tile
-        A.FUSE_UPSAMPLE = "auto"
+        A.FUSE_UPSAMPLE = False
     assert all(p.requires_grad for p in model.parameters())  # the attack restores the flags it froze
 
 

@@ -222,7 +222,8 @@ __device__ __forceinline__ void gemm_split_store_tile(const GemmSplitArgs& p, co
 
 // launcher of the ping-pong kernel (gemm_split_pp.hip); returns false when the variant is not built for this mode
 bool gemm_split_pp_launch(const GemmSplitArgs& p, int terms, int pro, bool fused, hipStream_t st);
-// launcher of the 256 x 256 kernel (gemm_split_big.hip): two terms, no prologue / fused extras, N % 256 == 0
-bool gemm_split_big_launch(GemmSplitArgs p, int terms, int batch, hipStream_t st);
+// launcher of the one-block-per-CU kernels (gemm_split_big.hip): two terms, no fused extras; shape 0 = 256 x 256 tiles
+// (N % 256 == 0, no prologue), shape 1 = 128 x 384 tiles (N % 384 == 0, any prologue)
+bool gemm_split_big_launch(GemmSplitArgs p, int terms, int batch, int shape, int pro, hipStream_t st);
 
 }  // namespace sea

@@ -567,6 +567,11 @@ static std::atomic<int> g_mfma_shape{[] {
 
 // tuning knob: MFMA fragment shape of sea_gemm_split* (32 = v_mfma_f32_32x32x16_*, 16 = v_mfma_f32_16x16x32_*); any other
 // value only queries.  Returns the previous shape.  Results of the two shapes differ in the last bits (summation order).
+static const int g_wide_min = [] {   // (A/B knob: smallest tile count for the 128 x 384 kernel; 0x7fffffff switches it off)
+  const char* e = getenv("SEA_GEMM_WIDE_MIN");
+  return e ? atoi(e) : 192;
+}();
+
 static std::atomic<int> g_pipeline{[] {
   const char* e = getenv("SEA_GEMM_PIPE");
   return (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 2;
@@ -774,11 +779,18 @@ static int gemm_split_impl(const float* A, int64_t lda, const void* Wp, float* C
   const int pro = p.a_gelu ? 2 : (p.a_gelu_grad_of ? (p.a_gate ? 3 : 1) : 0);
   const hipStream_t st = (hipStream_t)stream;
   const int pipe = g_pipeline.load(std::memory_order_relaxed);
-  // 256 x 256 tiles (gemm_split_big.hip) for the products that are bound by the bytes a CU pulls through its L1: many tiles,
-  // N a multiple of 256, plain epilogue.  pipe 3 forces them wherever they apply, pipe 2 takes them from 1024 tiles on.
-  if (!shape16 && (terms == 22 || terms == 2) && pro == 0 && !fused && (N % 256) == 0 && M >= 256 && (pipe == 2 || pipe == 3)) {
-    const int64_t big_tiles = (int64_t)((M + 255) / 256) * (N / 256) * batch;
-    if ((pipe == 3 || big_tiles >= 1024) && gemm_split_big_launch(p, terms, batch, st)) SEA_RETURN_LAST();
+  // One-block-per-CU kernels (gemm_split_big.hip) for the products that are bound by the bytes a CU pulls through its L1.
+  // pipe 3 forces them wherever they apply; pipe 2 takes 256 x 256 tiles from 1024 tiles on (the Winograd-domain products) and
+  // 128 x 384 tiles where they fill the chip in whole rounds (256 CUs: the 32 x 32-pixel stage's M = 8192 products).
+  if (!shape16 && (terms == 22 || terms == 2) && !fused && (pipe == 2 || pipe == 3)) {
+    const int64_t t256 = (N % 256) == 0 ? (int64_t)((M + 255) / 256) * (N / 256) * batch : 0;
+    const int64_t t384 = (N % 384) == 0 ? (int64_t)((M + 127) / 128) * (N / 384) * batch : 0;
+    if (pro == 0 && M >= 256 && t256 > 0 && (pipe == 3 ? t384 == 0 : t256 >= 1024) && gemm_split_big_launch(p, terms, batch, 0, 0, st))
+      SEA_RETURN_LAST();
+    // (one round of one block per CU: measured in the loop -- 39 / 48 / 45 us against 41 / 61 / 50 us for the plain / GELU' /
+    // GELU launches of the M = 8192 products; on two or more rounds the 128 x 128 kernels win, profiles/r5_gemm_wide_ab.md)
+    const bool wide_fits = t384 >= g_wide_min && t384 <= 256 && K >= 192;
+    if (t384 > 0 && M >= 128 && (pipe == 3 || wide_fits) && gemm_split_big_launch(p, terms, batch, 1, pro, st)) SEA_RETURN_LAST();
   }
   // per launch (pipe 2): the ping-pong kernel where it wins IN the attack loop (profiles/r5_gemm_pipe_ab.md): a VALU-heavy
   // prologue (GELU / GELU' / gate on A: hidden in its MFMA shadow) on a grid that fills two blocks per CU at least as

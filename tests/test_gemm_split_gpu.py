@@ -534,15 +534,18 @@ def test_pingpong_pipeline_gives_the_bits_of_the_single_stage_loop(N, M, K, Nn):
     assert (o1[22, "plain"].double() - ref).abs().max().item() <= 3e-6 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("G,M,K,Nn", [(3, 1024, 512, 512), (2, 700, 96, 256), (1, 300, 32, 768), (2, 2048, 160, 256)])
-def test_256x256_tile_kernel_gives_the_bits_of_the_128x128_kernels(N, G, M, K, Nn):
-    """sea_gemm_split_pipeline(3) (csrc/gemm_split_big.hip: 256 x 256 tiles, 8 waves, one block per CU; the Winograd-domain
-    products) against pipeline 0: same split, same MFMA order per accumulator -> the same bits, for fp16 x 2 and bf16 x 2,
-    bias / ReLU / out_amax, ragged M (rows past M load zeros through the buffer descriptor) and odd / single K-step counts"""
+@pytest.mark.parametrize("G,M,K,Nn", [(3, 1024, 512, 512), (2, 700, 96, 256), (1, 300, 32, 768), (2, 2048, 160, 256), (2, 1000, 384, 384),
+                                      (1, 515, 192, 1152)])
+def test_one_block_per_cu_kernels_give_the_bits_of_the_128x128_kernels(N, G, M, K, Nn):
+    """sea_gemm_split_pipeline(3) (csrc/gemm_split_big.hip: 8 waves, one block per CU; 256 x 256 tiles for the Winograd-domain
+    products, 128 x 384 tiles -- with the GELU / GELU' / gate prologues -- where N is a multiple of 384) against pipeline 0: same
+    split, same MFMA order per accumulator -> the same bits, for fp16 x 2 and bf16 x 2, bias / ReLU / out_amax, ragged M (rows
+    past M load zeros through the buffer descriptor) and odd / single K-step counts"""
     g = torch.Generator(device="cuda").manual_seed(M + K + Nn)
     A = torch.randn(G, M, K, generator=g, device="cuda") * torch.exp2(torch.randint(-6, 3, (G, M, 1), generator=g, device="cuda").float())
     W = torch.randn(G, Nn, K, generator=g, device="cuda") / K ** 0.5
     bias = torch.randn(Nn, generator=g, device="cuda")
+    tt = torch.randn(G, M, K, generator=g, device="cuda")
 
     def variants():
         outs = {}
@@ -550,6 +553,10 @@ def test_256x256_tile_kernel_gives_the_bits_of_the_128x128_kernels(N, G, M, K, N
             Wp = N.gemm_split_pack(W, terms=terms)
             outs[terms, "plain"] = N.gemm_split(A, Wp, groups=1)
             outs[terms, "bias_relu"] = N.gemm_split(A, Wp, bias=bias, relu=True, groups=1)
+            if Nn % 384 == 0:          # the prologues (128 x 384 tiles only)
+                outs[terms, "gelu"] = N.gemm_split(A, Wp, a_gelu=True, groups=1)
+                outs[terms, "gelu_grad"] = N.gemm_split(A, Wp, a_gelu_grad_of=tt, groups=1)
+                outs[terms, "gate"] = N.gemm_split(A, Wp, a_relu_gate=tt, groups=1)
         word = N.amax_word(A.device)
         outs[22, "out_amax"] = N.gemm_split(A, N.gemm_split_pack(W, terms=22), out_amax=word, groups=1).clone()
         outs[22, "out_amax_word"] = word.clone()

@@ -48,7 +48,7 @@ def _short_step_ms(steps=30):
     return ms
 
 
-@pytest.mark.parametrize("eps", [4.0, 8.0])
+@pytest.mark.parametrize("eps", [8.0, 4.0])   # (8 first: it runs the evaluation twice, so the process warm-up is not in its minimum)
 def test_configs1_full_sea_3x300_as_written(tmp_path, monkeypatch, eps):
     import yaml
     from semseg import attacker

@@ -58,21 +58,22 @@ import miou_ref as R
 pytestmark = pytest.mark.gpu
 pytest.importorskip("scipy", reason="the distribution tests (Mann-Whitney, Kolmogorov-Smirnov) need scipy")
 
-# Suite budget: the default `-m gpu` selection runs the eps-8 comparison on a FIXED subset of 256 images (the four parts that
-# have oneDNN-off re-runs first); SEA_MIOU_FULL=1 runs every committed part (the builder does, per round, and keeps the log
-# under profiles/).  Without the cap this file grows by 18 s per committed part and the suite towards the driver's limit.
+# Suite budget: the default `-m gpu` selection runs the eps-8 comparison on TEN committed parts (640 images, 57 s: the
+# set DESIGN 5 quotes); SEA_MIOU_FULL=1 runs every committed part (the builder does, per round, and keeps the log under
+# profiles/).  Without the cap this file grows by 5 s per committed part and the suite towards the driver's limit.  Round 5
+# tried a 4-part / 256-image default: on those four parts the device-minus-reference mean sits at z = -2.1 ... -2.75 depending
+# on the box (the attack amplifies last-bit differences, see below), which is a sampling fluctuation the 640-image set does not
+# show (z = -1.2) and made the 99 % assertion a coin toss -- a subset that small tests the sample, not the build.
 FULL = os.environ.get("SEA_MIOU_FULL", "0") == "1"
-SUBSET_PARTS = 4
+DEFAULT_PARTS = (0, 1, 2, 3, 4, 5, 8, 9, 10, 11)        # the ten parts committed when the default was fixed (round 5)
 _TABLES = {}     # (mode tag, eps, suffix, part) -> device tables: the control test re-uses the claim test's runs
 
 
 def _subset(eps255, suffix):
     plist = R.parts(eps255, suffix)
-    if FULL or len(plist) <= SUBSET_PARTS:
+    if FULL or len(plist) <= len(DEFAULT_PARTS):
         return plist
-    rerun = {p for p, _ in R.parts(eps255, suffix + "_nomkldnn")}
-    plist = sorted(plist, key=lambda pd: (pd[0] not in rerun, pd[0]))[:SUBSET_PARTS]
-    return sorted(plist, key=lambda pd: pd[0])
+    return [pd for pd in plist if pd[0] in DEFAULT_PARTS]
 
 
 @pytest.fixture(scope="module")
@@ -110,7 +111,7 @@ def _device_tables(model, eps255, plist, mode="shipped", suffix="", batch=R.PART
         t = {}
         # one batch of 64 images (the reference ran batches of 16: an image's trajectory depends on its own data, labels and
         # random starts only -- the controller is per image and the fp16 x 2 scales are per row / per image -- and 64 x 128^2
-        # pixels are what fills the GPU: 8 x 512^2)
+        # pixels are half the headline batch: 4 x 512^2)
         sea_evaluate(model, images, labels, w, eps255 / 255.0, int(d["n_iter"]), batch=batch, losses=R.LOSSES,
                      noise_fn=noise_fn, tables=t)
         _TABLES[key] = (torch.from_numpy(d["ints"]).long(), torch.from_numpy(d["unions"]).long(), t["inter"], t["union"])

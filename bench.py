@@ -130,18 +130,19 @@ def k2_cold_ms(N, run, logits_shape, C, HW):
 def model_gemm_roofline(N, model, x, ms_per_step):
     """The step's real bottleneck, next to K2's HBM roofline: the frozen-weight GEMM launches (M8, sea_gemm_split).  Eager
     (un-captured) forward + input-gradient passes of the model AFTER the timed region, with a HIP event pair around every
-    outermost `gemm_split` call on the launch stream.  Pass 1 finds the shapes; in passes 2 and 3 the LARGEST launch (most flop:
-    the Winograd-domain product) is issued ten times back to back inside its event pair, so that it is timed under sustained
-    matrix load like in the replayed loop (a single eager launch runs on an idle, higher-clocked chip and reads 10-15 % short).
-    Priced against the dense 16-bit MFMA peak: 2 G M K N flop x products (3 for fp16 x 2 / bf16 x 2: hi*hi', hi*mid', mid*hi')
-    / time per launch."""
+    outermost `gemm_split` call on the launch stream.  Pass 1 finds the shapes (and warms them); in passes 2 and 3 EVERY call is
+    issued ten times back to back inside its event pair (the calls only overwrite their outputs): a single eager launch is
+    timed wrongly in both directions -- a large one runs on an idle, higher-clocked chip and reads 10-15 % short, a small one
+    waits for the host between the start event and the kernel and reads up to 60 % long (38.8 us under rocprofv3, 61 us
+    between two events, for 8192 x 1536 x 384).  Priced against the dense 16-bit MFMA peak: 2 G M K N flop x products (3 for
+    fp16 x 2 / bf16 x 2: hi*hi', hi*mid', mid*hi') / time per launch."""
     orig, depth, rec, target, REPS = N.gemm_split, [0], {}, [None], 10
 
     def hooked(A, Wp, *a, **k):
         if depth[0]:
             return orig(A, Wp, *a, **k)
         key = (Wp.batch, A.shape[-2], Wp.K, Wp.N, Wp.terms)
-        reps = REPS if key == target[0] else 1
+        reps = REPS if target[0] is not None else 1
         depth[0] += 1
         try:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -192,8 +193,9 @@ def model_gemm_roofline(N, model, x, ms_per_step):
     out.update({"most_time_per_step": price(busiest), "all_gemm_split_ms_per_step": all_ms,
                 "all_gemm_split_share_of_step": all_ms / ms_per_step,
                 "measured": "HIP events around every outermost gemm_split call in eager forward + input-gradient passes after the "
-                            f"timed region; the largest launch {REPS} x back to back per event pair (sustained load); the other "
-                            "shapes singly (idle, higher-clocked chip between eager launches: their in-graph times are longer)"})
+                            f"timed region; every call {REPS} x back to back per event pair (sustained load, no host gap "
+                            "inside the pair after the first launch; launches shorter than the ~25 us the host needs per eager call "
+                            "still read long: rocprofv3's per-kernel times under profiles/ are the reference for those)"})
     return out
 
 

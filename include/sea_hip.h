@@ -304,6 +304,26 @@ int sea_layernorm_fwd(const float* x, const float* w, const float* b, float* y, 
 int sea_layernorm_bwd(const float* g, const float* x, const float* w, const float* mean, const float* rstd,
                       float* dx, int64_t rows, int C, void* stream);
 
+/* M9  (model side) the convolutional stem of the robust ConvNeXt backbones (backbones/convnext_orig.py:17-38:
+ * Conv2d(3,48,3,s2,p1) -> LayerNorm(channels_first, eps 1e-6) -> GELU -> Conv2d(48,96,3,s2,p1) -> LayerNorm -> GELU), for
+ * frozen parameters: forward and input gradient.  fp32 FMA in a fixed order (bitwise reproducible).  The image and its
+ * gradient are NCHW; the tensors between the two convolutions are NHWC (the library's fast layout for the 48 -> 96
+ * convolution, which stays a library call).
+ *   sea_stem_conv1_ln_gelu: x (B,3,H,W) NCHW -> y (B,Ho,Wo,CO) NHWC = conv(x) + bias, and, unless a == NULL, a = GELU(LN_c(y))
+ *                           (NHWC); Ho = (H-1)/2+1, Wo = (W-1)/2+1; w (CO,3,3,3); bias may be NULL; CO == 48.
+ *   sea_stem_conv1_bwd    : dy (B,Ho,Wo,CO) NHWC -> dx (B,3,H,W) NCHW, the input gradient of that convolution.
+ *   sea_ln_gelu_cl_fwd/bwd: a = GELU(LN over C of y) for y (B,HW,C) NHWC, C in {48, 96}; a / da are NHWC, or NCHW (B,C,HW)
+ *                           when a_nchw != 0; dy (NHWC) from da with the statistics recomputed from y (nothing else is saved
+ *                           by the forward).
+ * Anything else (other CO / C) returns 1 (invalid argument): the caller keeps its library path. */
+int sea_stem_conv1_ln_gelu(const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
+                           float* y, float* a, int B, int CO, int H, int W, float eps, void* stream);
+int sea_stem_conv1_bwd(const float* dy, const float* w, float* dx, int B, int CO, int H, int W, void* stream);
+int sea_ln_gelu_cl_fwd(const float* y, const float* gamma, const float* beta, float* a, int a_nchw, int B, int C, int64_t HW,
+                       float eps, void* stream);
+int sea_ln_gelu_cl_bwd(const float* da, int a_nchw, const float* y, const float* gamma, const float* beta, float* dy, int B,
+                       int C, int64_t HW, float eps, void* stream);
+
 /* M6  (model side) the FPN bottleneck without up-sampling its coarse inputs (uperforseg.py:255-262).  Channel
  * mixing commutes with bilinear up-sampling, so for an input that is an xs up-sampling (s >= 3) the nine 3x3
  * taps are applied as one GEMM at the coarse resolution, G = f @ W -> (B,h,w,9,C), and only a gather is left

@@ -37,6 +37,7 @@ SOURCES = [
     ("transpose_kernels.hip", ["-ffp-contract=off"]),
     ("wino_kernels.hip", []),
     ("ln_kernels.hip", []),
+    ("stem_kernels.hip", []),
     ("fpn_fused.hip", []),
     ("probe_kernels.hip", []),
     ("attention.hip", []),

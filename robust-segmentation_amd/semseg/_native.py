@@ -60,6 +60,10 @@ _SIGS = {
     "sea_upsample_bilinear_bwd": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "sea_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _vp]),
     "sea_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp]),
+    "sea_stem_conv1_ln_gelu": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "sea_stem_conv1_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "sea_ln_gelu_cl_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _f, _vp]),
+    "sea_ln_gelu_cl_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i64, _f, _vp]),
     "sea_wino_tiles": (_i64, [_i, _i, _i, _i]),
     "sea_wino_input_transform": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
     "sea_wino_filter_transform": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
@@ -529,6 +533,83 @@ def layernorm_backward(g, x, weight, mean, rstd):
     _check(lib().sea_layernorm_bwd(_p(_f32c(g)), _p(_f32c(x)), _p(_f32c(weight)), _p(mean), _p(rstd), _p(dx),
                                    x.numel() // Cc, Cc, _stream()), "sea_layernorm_bwd")
     return dx
+
+
+# ------------------------------------------------------------------------------------------------ M9
+STEM_CONV1_CHANNELS = (48,)
+LN_GELU_CL_CHANNELS = (48, 96)
+
+
+def _nhwc_dense(t):
+    """(B,C,H,W) tensor whose memory is dense NHWC (a 1 x 1 map, which is NCHW-contiguous as well, included)"""
+    return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)
+
+
+def _empty_cl(B, Cc, H, W, device):
+    return torch.empty((B, H, W, Cc), dtype=torch.float32, device=device).permute(0, 3, 1, 2)
+
+
+def stem_conv1_ln_gelu(x, weight, bias, gamma=None, beta=None, eps: float = 1e-6):
+    """x (B,3,H,W) NCHW -> (y, a): y = conv2d(x, weight (48,3,3,3), bias, stride 2, padding 1) and a = GELU(LayerNorm over the
+    channels of y) -- a is None when gamma is None (the convolution alone).  y and a are (B,48,Ho,Wo) tensors in
+    channels_last memory."""
+    _dev(x, weight, bias, gamma, beta)
+    if x.dim() != 4 or x.shape[1] != 3 or tuple(weight.shape[1:]) != (3, 3, 3) or weight.shape[0] not in STEM_CONV1_CHANNELS:
+        raise SeaNativeError("stem_conv1_ln_gelu: x (B,3,H,W) and weight (48,3,3,3) expected")
+    x = _f32c(x)
+    B, _, H, W = x.shape
+    CO = weight.shape[0]
+    y = _empty_cl(B, CO, (H - 1) // 2 + 1, (W - 1) // 2 + 1, x.device)
+    a = torch.empty_like(y) if gamma is not None else None     # (preserves the channels_last strides)
+    _check(lib().sea_stem_conv1_ln_gelu(_p(x), _p(_f32c(weight)), _p(_f32c(bias)) if bias is not None else None,
+                                        _p(_f32c(gamma)) if gamma is not None else None,
+                                        _p(_f32c(beta)) if gamma is not None else None, _p(y),
+                                        _p(a) if a is not None else None, B, CO, H, W, float(eps), _stream()),
+           "sea_stem_conv1_ln_gelu")
+    return y, a
+
+
+def stem_conv1_backward(dy, weight, H: int, W: int):
+    """input gradient (B,3,H,W) NCHW of the stride-2 3x3 stem convolution given dy (B,48,Ho,Wo) in channels_last memory"""
+    _dev(dy, weight)
+    B, CO, Ho, Wo = dy.shape
+    if (Ho, Wo) != ((H - 1) // 2 + 1, (W - 1) // 2 + 1) or CO not in STEM_CONV1_CHANNELS:
+        raise SeaNativeError("stem_conv1_backward: dy does not belong to an input of this size")
+    if dy.dtype != torch.float32 or not _nhwc_dense(dy):
+        raise SeaNativeError("stem_conv1_backward: dy must be float32 in channels_last memory")
+    dx = torch.empty((B, 3, H, W), dtype=torch.float32, device=dy.device)
+    _check(lib().sea_stem_conv1_bwd(_p(dy), _p(_f32c(weight)), _p(dx), B, CO, H, W, _stream()), "sea_stem_conv1_bwd")
+    return dx
+
+
+def ln_gelu_cl(y, gamma, beta, eps: float = 1e-6, out_nchw: bool = False):
+    """GELU(LayerNorm over dim 1) of a (B,C,H,W) fp32 tensor in channels_last memory, C in LN_GELU_CL_CHANNELS; the result is
+    NCHW-contiguous when ``out_nchw`` else channels_last"""
+    _dev(y, gamma, beta)
+    if y.dtype != torch.float32 or not _nhwc_dense(y) or y.shape[1] not in LN_GELU_CL_CHANNELS:
+        raise SeaNativeError("ln_gelu_cl: float32 (B,C,H,W) in channels_last memory with C in (48, 96) expected")
+    B, Cc, H, W = y.shape
+    a = torch.empty((B, Cc, H, W), dtype=torch.float32, device=y.device) if out_nchw else torch.empty_like(y)
+    _check(lib().sea_ln_gelu_cl_fwd(_p(y), _p(_f32c(gamma)), _p(_f32c(beta)), _p(a), int(out_nchw), B, Cc, H * W, float(eps),
+                                    _stream()), "sea_ln_gelu_cl_fwd")
+    return a
+
+
+def ln_gelu_cl_backward(da, y, gamma, beta, eps: float = 1e-6):
+    """d loss / d y (channels_last) of ``ln_gelu_cl`` (gamma, beta frozen); da is NCHW-contiguous or channels_last; the
+    statistics are recomputed from y"""
+    _dev(da, y, gamma, beta)
+    if da.dtype != torch.float32 or da.shape != y.shape or not _nhwc_dense(y):
+        raise SeaNativeError("ln_gelu_cl_backward: da float32 of y's shape, y in channels_last memory")
+    B, Cc, H, W = y.shape
+    # (a tensor with H = W = 1 or C = 1 is both: either reading is the same memory)
+    nchw = da.is_contiguous()
+    if not nchw and not _nhwc_dense(da):
+        raise SeaNativeError("ln_gelu_cl_backward: da must be NCHW-contiguous or channels_last")
+    dy = torch.empty_like(y)
+    _check(lib().sea_ln_gelu_cl_bwd(_p(da), int(nchw), _p(y), _p(_f32c(gamma)), _p(_f32c(beta)), _p(dy), B, Cc, H * W,
+                                    float(eps), _stream()), "sea_ln_gelu_cl_bwd")
+    return dy
 
 
 # ------------------------------------------------------------------------------------------------ M4

@@ -586,6 +586,60 @@ def _fast_layout_ok(x):
             and x.shape[1] % 4 == 0 and (x.shape[2] * x.shape[3]) % 4 == 0)
 
 
+# The stem through libsea_hip M9 (env SEA_FUSED_STEM=0: the library path): conv1 + LayerNorm + GELU in one kernel, a
+# LayerNorm + GELU kernel (statistics recomputed in the backward), and a direct input-gradient kernel for the 3-channel
+# convolution; NHWC from the first convolution on (the 48 -> 96 one stays a library call, fastest in that layout, and the
+# trunk's blocks run NHWC).  For frozen parameters only (no weight gradients are computed).
+USE_FUSED_STEM = os.environ.get("SEA_FUSED_STEM", "1") != "0"
+
+
+class _StemConv1LnGelu(torch.autograd.Function):
+    """GELU(LN_c(conv2d(x, w, b, stride 2, padding 1))) for the 3 -> 48 convolution of the stem (convnext_orig.py:22-24);
+    x NCHW, result in channels_last memory"""
+
+    @staticmethod
+    @_fp32_fwd
+    def forward(ctx, x, weight, bias, gamma, beta, eps):
+        from .. import _native as N
+        y, a = N.stem_conv1_ln_gelu(x.contiguous(), weight, bias, gamma, beta, eps)
+        ctx.save_for_backward(y, weight, gamma, beta)
+        ctx.eps, ctx.hw = eps, (x.shape[2], x.shape[3])
+        return a
+
+    @staticmethod
+    @_fp32_bwd
+    def backward(ctx, da):
+        from .. import _native as N
+        y, weight, gamma, beta = ctx.saved_tensors
+        if not (da.is_contiguous() or da.is_contiguous(memory_format=torch.channels_last)):
+            da = da.contiguous(memory_format=torch.channels_last)
+        dy = N.ln_gelu_cl_backward(da, y, gamma, beta, ctx.eps)
+        return N.stem_conv1_backward(dy, weight, *ctx.hw), None, None, None, None, None
+
+
+class _LnGeluCL(torch.autograd.Function):
+    """GELU(LayerNorm over the channels) of a tensor in channels_last memory, frozen affine parameters
+    (convnext_orig.py:31-32); the result stays channels_last (the trunk's blocks run NHWC: Block.forward)"""
+
+    @staticmethod
+    @_fp32_fwd
+    def forward(ctx, y, gamma, beta, eps):
+        from .. import _native as N
+        y = y.contiguous(memory_format=torch.channels_last)
+        ctx.save_for_backward(y, gamma, beta)
+        ctx.eps = eps
+        return N.ln_gelu_cl(y, gamma, beta, eps)
+
+    @staticmethod
+    @_fp32_bwd
+    def backward(ctx, da):
+        from .. import _native as N
+        y, gamma, beta = ctx.saved_tensors
+        if not (da.is_contiguous() or da.is_contiguous(memory_format=torch.channels_last)):
+            da = da.contiguous()
+        return N.ln_gelu_cl_backward(da, y, gamma, beta, ctx.eps), None, None, None
+
+
 class ConvStem(nn.Module):
     """"CVST" stem: two stride-2 3x3 convs (3->48->96) each followed by channel LN + GELU."""
 
@@ -596,8 +650,22 @@ class ConvStem(nn.Module):
             nn.Conv2d(width, 2 * width, 3, stride=2, padding=1), LayerNorm(2 * width, data_format="channels_first"),
             nn.GELU())
 
+    def _fused_ok(self, x):
+        from .. import _native as N
+        c1, n1, c2, n2 = self.stem[0], self.stem[1], self.stem[3], self.stem[4]
+        return (USE_FUSED_STEM and x.is_cuda and x.dim() == 4 and x.shape[1] == 3 and x.dtype == torch.float32
+                and c1.out_channels in N.STEM_CONV1_CHANNELS and c2.out_channels in N.LN_GELU_CL_CHANNELS
+                and not any(p.requires_grad for p in self.parameters())
+                and isinstance(self.stem[2], nn.GELU) and self.stem[2].approximate == "none"
+                and isinstance(self.stem[5], nn.GELU) and self.stem[5].approximate == "none"
+                and n1.data_format == "channels_first" and n2.data_format == "channels_first")
+
     def forward(self, x):
-        return self.stem(x)
+        if not self._fused_ok(x):
+            return self.stem(x)
+        c1, n1, c2, n2 = self.stem[0], self.stem[1], self.stem[3], self.stem[4]
+        a1 = _StemConv1LnGelu.apply(x, c1.weight, c1.bias, n1.weight, n1.bias, n1.eps)
+        return _LnGeluCL.apply(c2(a1), n2.weight, n2.bias, n2.eps)
 
 
 class Block(nn.Module):

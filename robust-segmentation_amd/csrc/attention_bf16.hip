@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256, TERMS == 2 ? 2 : 1) void attn_dkv_bf16_kernel(
 // precision and an absolute floor of 2^-38 of it below -- wide enough for scales that are BOUNDS rather than exact maxima:
 //   * row fragments (the lane's own Q / K / V / dO row, the B operand of the first products): the row's exact maximum,
 //     computed in the lane; the accumulator is multiplied back by the exact inverse;
-//   * staged 64 x 64 tiles (K, V in dQ; Q, dO in dK / dV): ONE scale per (image, head) from a 48-block pre-pass over the
+//   * staged 64 x 64 tiles (K, V in dQ; Q, dO in dK / dV): ONE scale per (image, head) from a pre-pass over the
 //     four tensors (attn_amax_bh_kernel): a tile's rows are the CONTRACTION index of the transposed products, so their scale
 //     must be uniform over everything an accumulator sums -- all tiles of the (image, head);
 //   * the accumulator operands of the transposed products: P <= 1 takes 2^14; dS = P (dP - delta) scale takes the bound
@@ -564,19 +564,29 @@ __device__ __forceinline__ void tr_times_acc_f16(const char* __restrict__ tr, in
   }
 }
 
-// float bits of max |q|, |k|, |v|, |dO| over the T rows of every (image, head): out[(b H + h) 4 + {0, 1, 2, 3}]
+// float bits of max |q|, |k|, |v|, |dO| over the T rows of every (image, head): out[(b H + h) 4 + {0, 1, 2, 3}].
+// grid (H, B, Z): block z takes rows [z T / Z, (z + 1) T / Z) and merges its maxima with atomicMax (float bits of
+// non-negative values order like unsigned integers), so `out` is zeroed by attn_zero_words_kernel first.  (Round 5's first
+// version ran ONE block per (image, head): 48 blocks on 256 CUs, 35 us per launch, 28 launches per Segmenter step = 7 % of it.)
+__global__ void attn_zero_words_kernel(uint32_t* __restrict__ p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+
+template <int NT>   // 3: q, k, v (forward); 4: + dO
 __global__ __launch_bounds__(256) void attn_amax_bh_kernel(AttnPtrsB p, int T, int H, const float* __restrict__ go,
                                                            uint32_t* __restrict__ out) {
   const int b = blockIdx.y, h = blockIdx.x;
+  const int r0 = (int)((int64_t)T * blockIdx.z / gridDim.z), r1 = (int)((int64_t)T * (blockIdx.z + 1) / gridDim.z);
   const float* src[4] = {p.q + (int64_t)b * p.sb + (int64_t)h * p.sh, p.k + (int64_t)b * p.sb + (int64_t)h * p.sh,
                          p.v + (int64_t)b * p.sb + (int64_t)h * p.sh,
-                         go ? go + ((int64_t)b * T) * (H * kD) + h * kD : p.v + (int64_t)b * p.sb + (int64_t)h * p.sh};   // (forward: no dO)
+                         NT == 4 ? go + ((int64_t)b * T) * (H * kD) + h * kD : nullptr};
   const int64_t stride[4] = {p.st, p.st, p.st, (int64_t)H * kD};
   uint32_t m[4] = {0, 0, 0, 0};
   const int d4 = threadIdx.x & 15;
-  for (int row = threadIdx.x >> 4; row < T; row += 16) {
+  for (int row = r0 + (threadIdx.x >> 4); row < r1; row += 16) {
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NT; ++w) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(src[w] + (int64_t)row * stride[w] + 4 * d4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -587,7 +597,7 @@ __global__ __launch_bounds__(256) void attn_amax_bh_kernel(AttnPtrsB p, int T, i
   }
   __shared__ uint32_t part[4][4];
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < NT; ++w) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const uint32_t other = (uint32_t)__shfl_xor((int)m[w], o, 64);
@@ -596,12 +606,24 @@ __global__ __launch_bounds__(256) void attn_amax_bh_kernel(AttnPtrsB p, int T, i
     if ((threadIdx.x & 63) == 0) part[w][threadIdx.x >> 6] = m[w];
   }
   __syncthreads();
-  if (threadIdx.x < 4) {
+  if (threadIdx.x < NT) {
     const int w = threadIdx.x;
     uint32_t r = part[w][0];
     for (int i = 1; i < 4; ++i) r = part[w][i] > r ? part[w][i] : r;
-    out[((int64_t)b * H + h) * 4 + w] = r;
+    atomicMax(out + ((int64_t)b * H + h) * 4 + w, r);
   }
+}
+
+static inline void attn_amax_launch(const AttnPtrsB& p, int B, int H, int T, const float* grad_out, uint32_t* amax_ws,
+                                    hipStream_t stream) {
+  const int words = 4 * B * H;
+  int Z = (T + 63) / 64;                 // >= 64 rows per block
+  Z = Z < 1 ? 1 : (Z > 16 ? 16 : Z);
+  hipLaunchKernelGGL(attn_zero_words_kernel, dim3((words + 255) / 256), dim3(256), 0, stream, amax_ws, words);
+  if (grad_out)
+    hipLaunchKernelGGL(attn_amax_bh_kernel<4>, dim3(H, B, Z), dim3(256), 0, stream, p, T, H, grad_out, amax_ws);
+  else
+    hipLaunchKernelGGL(attn_amax_bh_kernel<3>, dim3(H, B, Z), dim3(256), 0, stream, p, T, H, grad_out, amax_ws);
 }
 
 // ---- forward, fp16 x 2: the loop of attn_fwd_bf16_kernel with 22-bit operands in three products per pair ---------------------
@@ -883,7 +905,7 @@ int sea_attention_bwd_f16x2(const float* q, const float* k, const float* v, int6
     (void)hipFuncSetAttribute((const void*)attn_dq_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
     attr_set_dev[dev & 63] = true;
   }
-  hipLaunchKernelGGL(attn_amax_bh_kernel, dim3(H, B), block, 0, stream, p, T, H, grad_out, amax_ws);
+  attn_amax_launch(p, B, H, T, grad_out, amax_ws, stream);
   hipLaunchKernelGGL(attn_dq_f16_kernel, grid, block, lds_dq, stream, p, T, H, scale, grad_out, lse, delta, amax_ws, dq, gsb, gsh, gst);
   hipLaunchKernelGGL(attn_dkv_f16_kernel, grid, block, lds_dkv, stream, p, T, H, scale, grad_out, lse, delta, amax_ws, dk, dv, gsb, gsh,
                      gst);
@@ -895,7 +917,7 @@ int sea_attention_fwd_f16x2(const float* q, const float* k, const float* v, int6
                             float scale, uint32_t* amax_ws, float* out, float* lse, hipStream_t stream) {
   AttnPtrsB p{q, k, v, sb, sh, st};
   dim3 grid((T + 127) / 128, H, B), block(256);
-  hipLaunchKernelGGL(attn_amax_bh_kernel, dim3(H, B), block, 0, stream, p, T, H, (const float*)nullptr, amax_ws);
+  attn_amax_launch(p, B, H, T, nullptr, amax_ws, stream);
   hipLaunchKernelGGL(attn_fwd_f16_kernel, grid, block, 0, stream, p, T, H, scale, amax_ws, out, lse);
   return (int)hipGetLastError();
 }

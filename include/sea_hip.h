@@ -304,6 +304,12 @@ int sea_layernorm_fwd(const float* x, const float* w, const float* b, float* y, 
 int sea_layernorm_bwd(const float* g, const float* x, const float* w, const float* mean, const float* rstd,
                       float* dx, int64_t rows, int C, void* stream);
 
+/* M2'' (model side) adaptive average pooling of an NHWC fp32 map to oh x ow bins with ATen's bin rule (the pyramid pooling
+ * of the head, uperforseg.py:150-177: 16 x 16 -> 1, 2, 3, 6), forward and input gradient; one block per bin x 16 channel
+ * groups (ATen's NHWC kernel runs these maps on 8 blocks).  C % 4 == 0, oh <= H, ow <= W, dense tensors. */
+int sea_adaptive_avg_pool_nhwc_fwd(const float* x, float* out, int B, int C, int H, int W, int oh, int ow, void* stream);
+int sea_adaptive_avg_pool_nhwc_bwd(const float* g, float* dx, int B, int C, int H, int W, int oh, int ow, void* stream);
+
 /* M9  (model side) the convolutional stem of the robust ConvNeXt backbones (backbones/convnext_orig.py:17-38:
  * Conv2d(3,48,3,s2,p1) -> LayerNorm(channels_first, eps 1e-6) -> GELU -> Conv2d(48,96,3,s2,p1) -> LayerNorm -> GELU), for
  * frozen parameters: forward and input gradient.  fp32 FMA in a fixed order (bitwise reproducible).  The image and its

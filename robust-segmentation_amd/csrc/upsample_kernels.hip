@@ -621,6 +621,56 @@ __global__ __launch_bounds__(256) void upsample_nhwc_bwd_kernel(const float4* __
   }
 }
 
+// The same gather for SMALL inputs (the pyramid-pooling maps of the head: 1 x 1 ... 6 x 6 coarse pixels under a 16 x 16 output,
+// uperforseg.py:171-177): one lane per (coarse pixel, 4 channels) leaves 6 ... 216 blocks looping over footprints of up to
+// 16 x 16 pixels (71 us for 6 MB).  Here a block owns one coarse pixel x 16 channel groups and its 16 row-lanes take the
+// footprint's rows Ylo + r, Ylo + r + 16, ...; the 16 partial sums meet in LDS in a fixed order.
+__global__ __launch_bounds__(256) void upsample_nhwc_bwd_small_kernel(const float4* __restrict__ gy, float4* __restrict__ gx,
+                                                                      int CG, int h, int w, int H, int W, float rh, float rw,
+                                                                      int64_t gpg) {
+  __shared__ float4 part[16][16];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int cg = blockIdx.y * 16 + cl;
+  const int pix = blockIdx.x;               // (b, yq, xq)
+  const int xq = pix % w, yq = (pix / w) % h, b = pix / (w * h);
+  const int Ylo = first_dst_ge(yq - 1, rh, h, H), Yhi = first_dst_ge(yq + 1, rh, h, H);
+  const int Xlo = first_dst_ge(xq - 1, rw, w, W), Xhi = first_dst_ge(xq + 1, rw, w, W);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (cg < CG) {
+    const float4* gb = gy + (int64_t)b * H * W * gpg + cg;
+    for (int Y = Ylo + rl; Y < Yhi; Y += 16) {
+      const AxisMapU my = axis_map_u(Y, rh, h);
+      const float wy = ((my.i0 == yq) ? (1.f - my.lam) : 0.f) + ((my.i1 == yq) ? my.lam : 0.f);
+      if (wy == 0.f) continue;
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int X = Xlo; X < Xhi; ++X) {
+        const AxisMapU mx = axis_map_u(X, rw, w);
+        const float wx = ((mx.i0 == xq) ? (1.f - mx.lam) : 0.f) + ((mx.i1 == xq) ? mx.lam : 0.f);
+        const float4 g = gb[((int64_t)Y * W + X) * gpg];
+        r.x = fmaf(wx, g.x, r.x);
+        r.y = fmaf(wx, g.y, r.y);
+        r.z = fmaf(wx, g.z, r.z);
+        r.w = fmaf(wx, g.w, r.w);
+      }
+      acc.x = fmaf(wy, r.x, acc.x);
+      acc.y = fmaf(wy, r.y, acc.y);
+      acc.z = fmaf(wy, r.z, acc.z);
+      acc.w = fmaf(wy, r.w, acc.w);
+    }
+  }
+  part[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && cg < CG) {
+    float4 t = part[0][cl];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) {
+      const float4 o = part[r][cl];
+      t.x += o.x, t.y += o.y, t.z += o.z, t.w += o.w;
+    }
+    gx[(int64_t)pix * CG + cg] = t;
+  }
+}
+
 // Power-of-two factor: the footprint of input pixel (yq, xq) is the 2S x 2S window at (S*yq - S/2, S*xq - S/2) with the
 // separable constant weights of upsample_bwd_pow2_kernel; the rows are unrolled (2S independent 16-byte loads in flight
 // per lane instead of one dependent load per tap), no float index arithmetic.
@@ -859,6 +909,97 @@ extern "C" int sea_upsample_bilinear_nhwc_fwd(const float* x, const float* resid
   SEA_RETURN_LAST();
 }
 
+// ---- adaptive average pooling of an NHWC map to oh x ow bins (the pyramid pooling of the head, uperforseg.py:150-177:
+// 16 x 16 -> 1, 2, 3, 6), ATen's bin rule: rows [floor(i H / oh), ceil((i + 1) H / oh)).  ATen's NHWC kernel runs these on
+// 8 blocks (52 us for 6 MB); here a block owns one bin x 16 channel groups, 16 pixel-lanes stride through the bin's pixels
+// and the partial sums meet in LDS in a fixed order.
+namespace sea {
+__device__ __forceinline__ int bin_start(int i, int n_in, int n_out) { return (int)(((int64_t)i * n_in) / n_out); }
+__device__ __forceinline__ int bin_end(int i, int n_in, int n_out) { return (int)(((int64_t)(i + 1) * n_in + n_out - 1) / n_out); }
+
+__global__ __launch_bounds__(256) void adaptive_pool_nhwc_fwd_kernel(const float4* __restrict__ x, float4* __restrict__ out,
+                                                                     int CG, int H, int W, int oh, int ow) {
+  __shared__ float4 part[16][16];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int cg = blockIdx.y * 16 + cl;
+  const int bin = blockIdx.x;               // (b, i, j)
+  const int j = bin % ow, i = (bin / ow) % oh, b = bin / (ow * oh);
+  const int y0 = bin_start(i, H, oh), y1 = bin_end(i, H, oh), x0 = bin_start(j, W, ow), x1 = bin_end(j, W, ow);
+  const int bw = x1 - x0, n = (y1 - y0) * bw;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (cg < CG) {
+    const float4* xb = x + (int64_t)b * H * W * CG + cg;
+    for (int k = rl; k < n; k += 16) {
+      const int yy = y0 + k / bw, xx = x0 + k % bw;
+      const float4 v = xb[((int64_t)yy * W + xx) * CG];
+      acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+    }
+  }
+  part[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && cg < CG) {
+    float4 t = part[0][cl];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) {
+      const float4 o = part[r][cl];
+      t.x += o.x, t.y += o.y, t.z += o.z, t.w += o.w;
+    }
+    const float inv = 1.f / (float)n;
+    out[(int64_t)bin * CG + cg] = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+  }
+}
+
+// dx[b,y,x,:] = sum over the bins (i, j) that contain (y, x) of g[b,i,j,:] / |bin|   (at most 2 x 2 bins overlap a pixel)
+__global__ __launch_bounds__(256) void adaptive_pool_nhwc_bwd_kernel(const float4* __restrict__ g, float4* __restrict__ dx,
+                                                                     int CG, int H, int W, int oh, int ow, int64_t total) {
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(idx % CG);
+    const int64_t pix = idx / CG;
+    const int xx = (int)(pix % W), yy = (int)((pix / W) % H);
+    const int64_t b = pix / ((int64_t)W * H);
+    // candidate bins: the last one starting at or before the coordinate, and its predecessor
+    int i1 = (int)((((int64_t)yy + 1) * oh - 1) / H);
+    i1 = i1 > oh - 1 ? oh - 1 : i1;
+    int j1 = (int)((((int64_t)xx + 1) * ow - 1) / W);
+    j1 = j1 > ow - 1 ? ow - 1 : j1;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = (i1 > 0 ? i1 - 1 : 0); i <= i1; ++i) {
+      const int y0 = bin_start(i, H, oh), y1 = bin_end(i, H, oh);
+      if (yy < y0 || yy >= y1) continue;
+      for (int j = (j1 > 0 ? j1 - 1 : 0); j <= j1; ++j) {
+        const int x0 = bin_start(j, W, ow), x1 = bin_end(j, W, ow);
+        if (xx < x0 || xx >= x1) continue;
+        const float inv = 1.f / (float)((y1 - y0) * (x1 - x0));
+        const float4 v = g[(((int64_t)b * oh + i) * ow + j) * CG + cg];
+        acc.x = fmaf(v.x, inv, acc.x), acc.y = fmaf(v.y, inv, acc.y), acc.z = fmaf(v.z, inv, acc.z), acc.w = fmaf(v.w, inv, acc.w);
+      }
+    }
+    dx[idx] = acc;
+  }
+}
+}  // namespace sea
+
+// x (B,H,W,C) NHWC fp32 dense -> out (B,oh,ow,C): adaptive average pooling (ATen's bins); oh <= H, ow <= W
+extern "C" int sea_adaptive_avg_pool_nhwc_fwd(const float* x, float* out, int B, int C, int H, int W, int oh, int ow,
+                                              void* stream) {
+  SEA_CHECK_ARG(x && out && B > 0 && C > 0 && (C % 4) == 0 && H > 0 && W > 0 && oh > 0 && ow > 0 && oh <= H && ow <= W);
+  SEA_CHECK_ARG(((((uintptr_t)x) | ((uintptr_t)out)) & 15) == 0 && (int64_t)B * oh * ow < (1ll << 31));
+  hipLaunchKernelGGL(adaptive_pool_nhwc_fwd_kernel, dim3(B * oh * ow, (C / 4 + 15) / 16), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)x, (float4*)out, C / 4, H, W, oh, ow);
+  SEA_RETURN_LAST();
+}
+
+// g (B,oh,ow,C) -> dx (B,H,W,C): the input gradient of the pooling above
+extern "C" int sea_adaptive_avg_pool_nhwc_bwd(const float* g, float* dx, int B, int C, int H, int W, int oh, int ow,
+                                              void* stream) {
+  SEA_CHECK_ARG(g && dx && B > 0 && C > 0 && (C % 4) == 0 && H > 0 && W > 0 && oh > 0 && ow > 0 && oh <= H && ow <= W);
+  SEA_CHECK_ARG(((((uintptr_t)g) | ((uintptr_t)dx)) & 15) == 0);
+  const int64_t total = (int64_t)B * H * W * (C / 4);
+  hipLaunchKernelGGL(adaptive_pool_nhwc_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)g, (float4*)dx, C / 4, H, W, oh, ow, total);
+  SEA_RETURN_LAST();
+}
+
 extern "C" int sea_upsample_bilinear_nhwc_bwd(const float* gy, float* gx, int B, int C, int h, int w, int H, int W,
                                               int64_t gy_pixel_stride, void* stream) {
   SEA_CHECK_ARG(gy && gx && B > 0 && C > 0 && (C % 4) == 0 && h > 0 && w > 0 && H >= h && W >= w);
@@ -876,6 +1017,10 @@ extern "C" int sea_upsample_bilinear_nhwc_bwd(const float* gy, float* gx, int B,
     SEA_LAUNCH_NHWC_BWD(4);
   } else if (S == 8) {
     SEA_LAUNCH_NHWC_BWD(8);
+  } else if (total < 65536 && (int64_t)B * h * w < 65536) {
+    hipLaunchKernelGGL(upsample_nhwc_bwd_small_kernel, dim3(B * h * w, (C / 4 + 15) / 16), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)gy, (float4*)gx, C / 4, h, w, H, W, (float)h / (float)H, (float)w / (float)W,
+                       gy_pixel_stride / 4);
   } else {
     hipLaunchKernelGGL(upsample_nhwc_bwd_kernel, dim3(grid_for_xcd(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)gy, (float4*)gx, C / 4, h, w, H, W, (float)h / (float)H, (float)w / (float)W,

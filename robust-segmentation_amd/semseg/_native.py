@@ -60,6 +60,8 @@ _SIGS = {
     "sea_upsample_bilinear_bwd": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "sea_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _vp]),
     "sea_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp]),
+    "sea_adaptive_avg_pool_nhwc_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "sea_adaptive_avg_pool_nhwc_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "sea_stem_conv1_ln_gelu": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "sea_stem_conv1_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sea_ln_gelu_cl_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _f, _vp]),
@@ -533,6 +535,32 @@ def layernorm_backward(g, x, weight, mean, rstd):
     _check(lib().sea_layernorm_bwd(_p(_f32c(g)), _p(_f32c(x)), _p(_f32c(weight)), _p(mean), _p(rstd), _p(dx),
                                    x.numel() // Cc, Cc, _stream()), "sea_layernorm_bwd")
     return dx
+
+
+# ------------------------------------------------------------------------------------------------ M2''
+def adaptive_avg_pool_nhwc(x, oh: int, ow: int):
+    """adaptive average pooling (ATen's bins) of a dense channels_last (B,C,H,W) fp32 tensor -> channels_last (B,C,oh,ow)"""
+    _dev(x)
+    if x.dtype != torch.float32 or cl_pixel_stride(x) != x.shape[1]:
+        raise SeaNativeError("adaptive_avg_pool_nhwc: dense channels_last float32 (B,C,H,W) with C % 4 == 0 expected")
+    B, Cc, H, W = x.shape
+    out = torch.empty((B, oh, ow, Cc), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
+    _check(lib().sea_adaptive_avg_pool_nhwc_fwd(_p(x), _p(out), B, Cc, H, W, oh, ow, _stream()), "sea_adaptive_avg_pool_nhwc_fwd")
+    return out
+
+
+def adaptive_avg_pool_nhwc_backward(g, H: int, W: int):
+    """input gradient (channels_last (B,C,H,W)) of ``adaptive_avg_pool_nhwc`` given g (B,C,oh,ow)"""
+    _dev(g)
+    B, Cc, oh, ow = g.shape
+    gn = g.permute(0, 2, 3, 1)
+    if g.dtype != torch.float32:
+        raise SeaNativeError("adaptive_avg_pool_nhwc_backward: float32 expected")
+    if not gn.is_contiguous():
+        gn = gn.contiguous()
+    dx = torch.empty((B, H, W, Cc), dtype=torch.float32, device=g.device)
+    _check(lib().sea_adaptive_avg_pool_nhwc_bwd(_p(gn), _p(dx), B, Cc, H, W, oh, ow, _stream()), "sea_adaptive_avg_pool_nhwc_bwd")
+    return dx.permute(0, 3, 1, 2)
 
 
 # ------------------------------------------------------------------------------------------------ M9

@@ -1209,6 +1209,36 @@ def _fpn_fusable(mod, outs):
                     for o in outs[1:]))
 
 
+USE_HIP_ADAPTIVE_POOL = os.environ.get("SEA_HIP_POOL", "1") != "0"
+
+
+class _AdaptivePoolCL(torch.autograd.Function):
+    """nn.AdaptiveAvgPool2d(s) of a dense channels_last map through libsea_hip (no parameters: training and attack alike)"""
+
+    @staticmethod
+    @_fp32_fwd
+    def forward(ctx, x, oh, ow):
+        from .. import _native as N
+        ctx.hw = (x.shape[2], x.shape[3])
+        return N.adaptive_avg_pool_nhwc(x, oh, ow)
+
+    @staticmethod
+    @_fp32_bwd
+    def backward(ctx, g):
+        from .. import _native as N
+        return N.adaptive_avg_pool_nhwc_backward(g, *ctx.hw), None, None
+
+
+def _adaptive_pool(pool: nn.AdaptiveAvgPool2d, x):
+    from .. import _native as N
+    s = pool.output_size
+    oh, ow = (s, s) if isinstance(s, int) else s
+    if (USE_HIP_ADAPTIVE_POOL and x.is_cuda and x.dtype == torch.float32 and oh is not None and ow is not None
+            and oh <= x.shape[2] and ow <= x.shape[3] and N.cl_pixel_stride(x) == x.shape[1]):
+        return _AdaptivePoolCL.apply(x, oh, ow)
+    return pool(x)
+
+
 class PyramidPooling(nn.Module):
     """Children "0".."3", each Sequential-like [AdaptiveAvgPool2d(s), ConvModule] with children "0","1"."""
 
@@ -1223,7 +1253,7 @@ class PyramidPooling(nn.Module):
 
     def pooled(self, x):
         """the pooled + projected maps at their own (1, 2, 3, 6) resolutions"""
-        return [getattr(getattr(self, str(i)), "1")(getattr(getattr(self, str(i)), "0")(x)) for i in range(self.n)]
+        return [getattr(getattr(self, str(i)), "1")(_adaptive_pool(getattr(getattr(self, str(i)), "0"), x)) for i in range(self.n)]
 
     def forward(self, x):
         return [_up(p, x.shape[2:]) for p in self.pooled(x)]

@@ -432,6 +432,8 @@ def test_upsample_bilinear_forward_backward(N, case):
                                   (1, 4, 1, 1, 16, 16), (1, 8, 3, 3, 16, 16), (2, 4, 6, 6, 16, 16),
                                   (1, 8, 30, 30, 119, 119), (1, 4, 13, 11, 50, 45), (1, 4, 9, 7, 9, 7),
                                   (2, 512, 4, 4, 8, 8),
+                                  # the pyramid-pooling maps: block-per-coarse-pixel backward, ragged channel groups
+                                  (2, 768, 1, 1, 16, 16), (2, 72, 3, 3, 16, 16), (1, 768, 6, 6, 16, 16), (1, 20, 5, 7, 23, 31),
                                   # power-of-two factors with edges everywhere (specialised NHWC kernels)
                                   (1, 4, 2, 3, 8, 12), (1, 8, 3, 2, 24, 16), (1, 4, 5, 1, 10, 2), (1, 4, 1, 5, 4, 20)])
 def test_upsample_bilinear_channels_last(N, case):

@@ -2,7 +2,7 @@
 # final evidence of round 5: tests with printed values, benches of the model configs, rocprofv3 summaries
 #   gpurun --timeout 3000 -- 'bash devtools/collect_round5_final.sh'
 cd ${GRAFT_REPO_ROOT:-.}
-O=gpurun_out/r5final5
+O=gpurun_out/r5final6
 mkdir -p $O
 # the rocprofv3 summaries first: collect_profiles.sh ends by copying profiles/r5_* (the fresh summaries AND every older committed
 # r5 file) into gpurun_out/; copied into $O here, BEFORE the runs below write their logs, so that a fresh log replaces a
@@ -25,7 +25,7 @@ python bench.py --steps 20 --warmup 5 --no-cpu-baseline --backbone ConvNeXt-S_CV
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --backbone vit_small_patch16_224 --classes 151 > $O/r5_bench_vits_c151.log 2>/dev/null; cut -c1-220 $O/r5_bench_vits_c151.log | tail -1
 SEA_ATTN_TERMS=3 SEA_ATTN_TERMS_BWD=3 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --sustain 0 --backbone vit_small_patch16_224 --classes 151 > $O/r5_bench_vits_c151_attn_bf16x3.log 2>/dev/null; cut -c1-220 $O/r5_bench_vits_c151_attn_bf16x3.log | tail -1
 python devtools/pirat_bench.py > $O/r5_pirat_config4_fp32_vs_bf16.log 2>&1; tail -2 $O/r5_pirat_config4_fp32_vs_bf16.log | cut -c1-400
-bash devtools/prof_bench_steady.sh r5final5/r5_grid > /dev/null 2>&1; head -3 $O/r5_grid_by_grid.txt
+bash devtools/prof_bench_steady.sh r5final6/r5_grid > /dev/null 2>&1; head -3 $O/r5_grid_by_grid.txt
 python devtools/gemm_pipe_ab.py 22 > $O/r5_gemm_pipe_ab.log 2>&1; tail -1 $O/r5_gemm_pipe_ab.log
 rm -f gpurun_out/gemm_pmc/summary.txt
 bash devtools/gemm_split_pmc.sh 36 8192 512 512 22 > /dev/null 2>&1; bash devtools/gemm_split_pmc.sh 1 8192 384 1536 22 > /dev/null 2>&1

@@ -304,6 +304,13 @@ int sea_layernorm_fwd(const float* x, const float* w, const float* b, float* y, 
 int sea_layernorm_bwd(const float* g, const float* x, const float* w, const float* mean, const float* rstd,
                       float* dx, int64_t rows, int C, void* stream);
 
+/* M1w (model side, training) weight and bias gradient of the NHWC depthwise 7x7: gw (C,7,7), gb (C) or NULL from x and gy
+ * (B,H,W,C) dense fp32 (PIR-AT's outer backward; convnext_orig.py:55-57).  Deterministic two-pass sum (per-tile partial
+ * sums in `ws`, sea_dwconv7x7_nhwc_wgrad_workspace(B, C, H) floats, then the tiles in index order).  C % 4 == 0. */
+int64_t sea_dwconv7x7_nhwc_wgrad_workspace(int B, int C, int H);
+int sea_dwconv7x7_nhwc_wgrad(const float* x, const float* gy, float* gw, float* gb, float* ws, int B, int C, int H, int W,
+                             void* stream);
+
 /* M2'' (model side) adaptive average pooling of an NHWC fp32 map to oh x ow bins with ATen's bin rule (the pyramid pooling
  * of the head, uperforseg.py:150-177: 16 x 16 -> 1, 2, 3, 6), forward and input gradient; one block per bin x 16 channel
  * groups (ATen's NHWC kernel runs these maps on 8 blocks).  C % 4 == 0, oh <= H, ow <= W, dense tensors. */

@@ -298,6 +298,149 @@ extern "C" int sea_dwconv7x7_nhwc_add(const float* x, const float* wt, const flo
   SEA_RETURN_LAST();
 }
 
+// ---- weight and bias gradient of the NHWC depthwise 7x7 (PIR-AT's outer backward, train_rob_seg.py:326-363 through
+// convnext_orig.py:55-57):  gw[c,ky,kx] = sum_{b,y,x} x[b, y+ky-3, x+kx-3, c] gy[b,y,x,c],  gb[c] = sum gy[b,y,x,c].
+// The library's kernel for it (CK batched GEMM "bwd_weight") takes 620 us per layer: 33 layers = 20 ms = 11 % of the bf16
+// outer step for 0.6 GFLOP each.  Here: a block owns (image, R rows, <= 64 channel quads); its seven waves take one tap row
+// ky each, a lane 4 channels (and every PL-th pixel group of the tile when fewer than 64 quads exist).  Partial sums per block
+// go to a workspace (tiles x 50 x C: 49 taps + the bias row), two more launches add the tiles in index order (32 chunks, then
+// the chunks): deterministic, unlike an atomic accumulation.
+namespace sea {
+__global__ __launch_bounds__(448) void dwconv7x7_nhwc_wgrad_partial_kernel(const float4* __restrict__ x,
+                                                                           const float4* __restrict__ gy,
+                                                                           float4* __restrict__ ws, int CQ, int H, int W,
+                                                                           int R, int tiles_per_image) {
+  const int lane = threadIdx.x & 63, ky = threadIdx.x >> 6;          // 7 waves: tap row
+  const int c0 = blockIdx.y * 64;
+  const int CQL = (CQ - c0) < 64 ? (CQ - c0) : 64;                   // channel quads of this block
+  const int PL = 64 / CQL;                                           // pixel lanes per wave
+  const int cl = lane % CQL, pl = lane / CQL;
+  const bool active = pl < PL;
+  const int tile = blockIdx.x, b = tile / tiles_per_image, r0 = (tile % tiles_per_image) * R;
+  const int r1 = (r0 + R) < H ? (r0 + R) : H;
+  const int cq = c0 + cl;
+  const float4* xb = x + (int64_t)b * H * W * CQ + cq;
+  const float4* gb = gy + (int64_t)b * H * W * CQ + cq;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 acc[7], accb = zero;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) acc[k] = zero;
+  if (active) {
+    // a lane walks groups of FOUR pixels along a row: 4 loads of gy and a sliding window of 10 loads of x feed 112 FMAs
+    // (one pixel per step was a chain of memory round trips: 422 us at 128 x 128 x 96)
+    const int GW = (W + 3) / 4, ngroups = (r1 - r0) * GW;
+    for (int q = pl; q < ngroups; q += PL) {
+      const int yy = r0 + q / GW, x0 = (q % GW) * 4;
+      const int ys = yy + ky - 3;
+      const bool row_ok = ys >= 0 && ys < H;
+      const float4* grow = gb + (int64_t)yy * W * CQ;
+      const float4* row = xb + (int64_t)(row_ok ? ys : yy) * W * CQ;
+      float4 g[4], v[10];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] = (x0 + j < W) ? grow[(int64_t)(x0 + j) * CQ] : zero;
+#pragma unroll
+      for (int j = 0; j < 10; ++j) {
+        const int xs = x0 + j - 3;
+        v[j] = (row_ok && xs >= 0 && xs < W) ? row[(int64_t)xs * CQ] : zero;
+      }
+      if (ky == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) accb.x += g[j].x, accb.y += g[j].y, accb.z += g[j].z, accb.w += g[j].w;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+          acc[k].x = fmaf(v[j + k].x, g[j].x, acc[k].x), acc[k].y = fmaf(v[j + k].y, g[j].y, acc[k].y);
+          acc[k].z = fmaf(v[j + k].z, g[j].z, acc[k].z), acc[k].w = fmaf(v[j + k].w, g[j].w, acc[k].w);
+        }
+    }
+  }
+  // pixel lanes of a channel quad (lanes cl + s * CQL) are added into lane cl in the order s = 1, 2, ...
+  for (int s2 = 1; s2 < PL; ++s2) {
+    const int src = cl + s2 * CQL;
+    const bool take = pl == 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      const float tx = __shfl(acc[k].x, src, 64), ty = __shfl(acc[k].y, src, 64), tz = __shfl(acc[k].z, src, 64),
+                  tw = __shfl(acc[k].w, src, 64);
+      if (take) acc[k].x += tx, acc[k].y += ty, acc[k].z += tz, acc[k].w += tw;
+    }
+    const float tx = __shfl(accb.x, src, 64), ty = __shfl(accb.y, src, 64), tz = __shfl(accb.z, src, 64),
+                tw = __shfl(accb.w, src, 64);
+    if (take) accb.x += tx, accb.y += ty, accb.z += tz, accb.w += tw;
+  }
+  if (lane < CQL) {
+    float4* wt = ws + (int64_t)tile * 50 * CQ + cq;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) wt[(int64_t)(ky * 7 + k) * CQ] = acc[k];
+    if (ky == 0) wt[(int64_t)49 * CQ] = accb;
+  }
+}
+
+// level 1: chunk z of the tiles -> ws2[z][50 C]; level 2 (chunks == 1 launch): gw (C,7,7) and gb (C).  Fixed order both times.
+__global__ __launch_bounds__(256) void dwconv7x7_nhwc_wgrad_reduce_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                                          float* __restrict__ gw, float* __restrict__ gb, int C,
+                                                                          int n, int per_chunk) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;   // (t, c), c fastest
+  if (idx >= 50 * C) return;
+  const int i0 = blockIdx.y * per_chunk, i1 = (i0 + per_chunk) < n ? (i0 + per_chunk) : n;
+  float s = 0.f;
+#pragma unroll 8
+  for (int i = i0; i < i1; ++i) s += src[(int64_t)i * 50 * C + idx];
+  if (dst != nullptr) {
+    dst[(int64_t)blockIdx.y * 50 * C + idx] = s;
+    return;
+  }
+  const int t = idx / C, c = idx - t * C;
+  if (t < 49)
+    gw[c * 49 + t] = s;
+  else if (gb != nullptr)
+    gb[c] = s;
+}
+}  // namespace sea
+
+// rows per tile: as many blocks as the chip holds at once (4 per CU), the work of a block being a chain of round trips
+static inline int dw_wgrad_rows(int B, int C, int H) {
+  const int chunks = (C / 4 + 63) / 64;
+  int R = (int)(((int64_t)B * H * chunks) / 1024);
+  return R < 1 ? 1 : (R > 8 ? 8 : R);
+}
+static inline int dw_wgrad_chunks(int tiles) { return tiles >= 64 ? 32 : 1; }
+
+// floats of workspace for sea_dwconv7x7_nhwc_wgrad
+extern "C" int64_t sea_dwconv7x7_nhwc_wgrad_workspace(int B, int C, int H) {
+  if (B <= 0 || C <= 0 || H <= 0) return 0;
+  const int R = dw_wgrad_rows(B, C, H);
+  const int64_t tiles = (int64_t)B * ((H + R - 1) / R);
+  return (tiles + 32) * 50 * C;
+}
+
+// x, gy (B,H,W,C) NHWC fp32 dense -> gw (C,7,7) [= the (C,1,7,7) weight gradient], gb (C) or NULL; ws: workspace floats
+extern "C" int sea_dwconv7x7_nhwc_wgrad(const float* x, const float* gy, float* gw, float* gb, float* ws, int B, int C,
+                                        int H, int W, void* stream) {
+  SEA_CHECK_ARG(x && gy && gw && ws && B > 0 && C > 0 && (C % 4) == 0 && H > 0 && W > 0);
+  SEA_CHECK_ARG(((((uintptr_t)x) | ((uintptr_t)gy) | ((uintptr_t)ws)) & 15) == 0);
+  const int R = dw_wgrad_rows(B, C, H), tpi = (H + R - 1) / R;
+  SEA_CHECK_ARG((int64_t)B * tpi < (1ll << 31));
+  const int tiles = B * tpi, chunks = dw_wgrad_chunks(tiles), per = (tiles + chunks - 1) / chunks;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(dwconv7x7_nhwc_wgrad_partial_kernel, dim3(tiles, (C / 4 + 63) / 64), dim3(448), 0, st, (const float4*)x,
+                     (const float4*)gy, (float4*)ws, C / 4, H, W, R, tpi);
+  const dim3 g1((50 * C + 255) / 256, chunks), g2((50 * C + 255) / 256, 1);
+  if (chunks > 1) {
+    float* ws2 = ws + (int64_t)tiles * 50 * C;
+    hipLaunchKernelGGL(dwconv7x7_nhwc_wgrad_reduce_kernel, g1, dim3(256), 0, st, (const float*)ws, ws2, (float*)nullptr,
+                       (float*)nullptr, C, tiles, per);
+    hipLaunchKernelGGL(dwconv7x7_nhwc_wgrad_reduce_kernel, g2, dim3(256), 0, st, (const float*)ws2, (float*)nullptr, gw, gb, C,
+                       chunks, chunks);
+  } else {
+    hipLaunchKernelGGL(dwconv7x7_nhwc_wgrad_reduce_kernel, g2, dim3(256), 0, st, (const float*)ws, (float*)nullptr, gw, gb, C, tiles,
+                       tiles);
+  }
+  SEA_RETURN_LAST();
+}
+
 extern "C" int sea_dwconv7x7_nhwc(const float* x, const float* wt, const float* bias, float* y, int B, int C, int H,
                                   int W, int flip, void* stream) {
   return sea_dwconv7x7_nhwc_add(x, wt, bias, nullptr, y, B, C, H, W, flip, stream);

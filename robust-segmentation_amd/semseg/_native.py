@@ -60,6 +60,8 @@ _SIGS = {
     "sea_upsample_bilinear_bwd": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "sea_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _vp]),
     "sea_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp]),
+    "sea_dwconv7x7_nhwc_wgrad_workspace": (_i64, [_i, _i, _i]),
+    "sea_dwconv7x7_nhwc_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sea_adaptive_avg_pool_nhwc_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "sea_adaptive_avg_pool_nhwc_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "sea_stem_conv1_ln_gelu": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
@@ -727,6 +729,21 @@ def dwconv7x7_nhwc(x, wt, bias=None, flip: bool = False, addend=None):
     _check(lib().sea_dwconv7x7_nhwc_add(_p(_f32c(x)), _p(_f32c(wt)), _p(bias), _p(addend), _p(y), B, Cc, H, W, int(flip),
                                         _stream()), "sea_dwconv7x7_nhwc_add")
     return y
+
+
+def dwconv7x7_nhwc_weight_grad(x, gy, want_bias: bool = True):
+    """(gw (C,1,7,7), gb (C) or None): weight / bias gradient of the depthwise 7x7 on (B,H,W,C) contiguous fp32 tensors"""
+    _dev(x, gy)
+    B, H, W, Cc = x.shape
+    if gy.shape != x.shape or Cc % 4:
+        raise SeaNativeError("dwconv7x7_nhwc_weight_grad: x and gy (B,H,W,C) of one shape, C % 4 == 0")
+    L = lib()
+    ws = torch.empty(int(L.sea_dwconv7x7_nhwc_wgrad_workspace(B, Cc, H)), dtype=torch.float32, device=x.device)
+    gw = torch.empty((Cc, 1, 7, 7), dtype=torch.float32, device=x.device)
+    gb = torch.empty(Cc, dtype=torch.float32, device=x.device) if want_bias else None
+    _check(L.sea_dwconv7x7_nhwc_wgrad(_p(_f32c(x)), _p(_f32c(gy)), _p(gw), _p(gb), _p(ws), B, Cc, H, W, _stream()),
+           "sea_dwconv7x7_nhwc_wgrad")
+    return gw, gb
 
 
 # ------------------------------------------------------------------------------------------------ M3

@@ -149,6 +149,18 @@ class _DwConv7x7(torch.autograd.Function):
         return gx, gw, gb
 
 
+USE_HIP_DW_WGRAD = os.environ.get("SEA_HIP_DW_WGRAD", "1") != "0"
+
+
+def _dw_weight_grad(x, weight, gy, want_bias):
+    """weight (and bias) gradient of the NHWC depthwise 7x7: libsea_hip M1w, or the library (SEA_HIP_DW_WGRAD=0)"""
+    from .. import _native as N
+    if USE_HIP_DW_WGRAD and x.is_cuda and x.dtype == torch.float32 and gy.dtype == torch.float32 and x.shape[-1] % 4 == 0:
+        return N.dwconv7x7_nhwc_weight_grad(x.contiguous(), gy, want_bias)
+    gw = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2), weight.shape, gy.permute(0, 3, 1, 2), padding=3, groups=x.shape[-1])
+    return gw, (gy.sum((0, 1, 2)) if want_bias else None)
+
+
 class _DwConv7x7NHWC(torch.autograd.Function):
     """Same layer on a (B,H,W,C) contiguous tensor (channels_last trunk): nothing in the block changes
     layout any more."""
@@ -171,9 +183,8 @@ class _DwConv7x7NHWC(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = N.dwconv7x7_nhwc(gy, wt, None, flip=True)
         if ctx.needs_input_grad[1]:
-            gw = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2), weight.shape, gy.permute(0, 3, 1, 2), padding=3,
-                                             groups=x.shape[-1])
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gw, gb = _dw_weight_grad(x, weight, gy, ctx.has_bias and ctx.needs_input_grad[2])
+        elif ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum((0, 1, 2))
         return gx, gw, gb, None
 
@@ -208,9 +219,8 @@ class _DwConv7x7NHWCSkip(torch.autograd.Function):
                 add = g_skip if (g_skip.is_contiguous() and g_skip.dtype == torch.float32) else g_skip.float().contiguous()
             gx = N.dwconv7x7_nhwc(gy, wt, None, flip=True, addend=add)
         if ctx.needs_input_grad[1]:
-            gw = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2), weight.shape, gy.permute(0, 3, 1, 2), padding=3,
-                                             groups=x.shape[-1])
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gw, gb = _dw_weight_grad(x, weight, gy, ctx.has_bias and ctx.needs_input_grad[2])
+        elif ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum((0, 1, 2))
         return gx, gw, gb, None
 

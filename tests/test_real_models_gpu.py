@@ -75,9 +75,22 @@ def test_step_pins_loss_accuracy_gradient(ctx, case, fused):
             got = grad.flatten()[g["grad_idx"].cuda()].cpu()
             ref = g[key + "_grad"]
             big = ref.abs() > 1e-2 * float(g[key + "_gradmax"])
+            # Pixels whose two best logits are closer than a few ulps of the logit scale are TIES: no implementation reproduces
+            # the reference's arg-max there, and a pixel that changes sides switches its whole loss term on or off (the masked
+            # losses) -- on this randomly initialised model every pixel's term has the same size, so F such pixels of N move
+            # the gradient by sqrt(F / N) of its norm: 2 of 524 288 = 1.95e-3, which is what round 5's stem kernels (as
+            # accurate against float64 as the library's: devtools/stem_accuracy_probe.py) measured where the library path has
+            # 5e-4 (devtools/grad_flip_probe.py: the two pixels have logit gaps of 1.5e-8 and 3e-8).  The bound is the
+            # arithmetic bound of before, 2e-3, plus in quadrature the ties that exist on the device, at most the 16 pixels
+            # the n_correct bound above allows.
+            full = logits.detach() if logits.shape[-1] == xp.shape[-1] else torch.nn.functional.interpolate(
+                logits.detach().float(), size=xp.shape[-2:], mode="bilinear", align_corners=False)
+            top2 = full.float().topk(2, dim=1).values
+            ties = int(((top2[:, 0] - top2[:, 1]) <= 5e-7 * float(g["logit_absmax"])).sum())
+            del full, top2
             # K1 only uses sign(grad): the sign must agree wherever the gradient is not at rounding level
-            B.check(f"{key}: gradient rel. L2 error   (round 4, fp16x2 input gradient: measured <= 5.8e-4; round 3, bf16x2: 2.5e-3)",
-                    (got - ref).norm() / ref.norm(), 2e-3)
+            B.check(f"{key}: gradient rel. L2 error   ({ties} tie pixels; round 4 measured <= 5.8e-4 without a flipped tie; round 3, bf16x2: 2.5e-3)",
+                    (got - ref).norm() / ref.norm(), (2e-3 ** 2 + min(ties, 16) / (xp.shape[0] * HW)) ** 0.5)
             B.check(f"{key}: sign mismatch where |g| > 1e-2 max", (torch.sign(got[big]) != torch.sign(ref[big])).float().mean(),
                     1e-3)
     B.report()

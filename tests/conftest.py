@@ -28,11 +28,12 @@ def pytest_collection_modifyitems(config, items):
 
 
 # Suite budget (round 5): the driver gives `pytest -m gpu` 1200 s.  No single GPU test of the default selection may take more
-# than SEA_TEST_MAX_SECONDS (default 120; the builder's full-set runs use SEA_MIOU_FULL=1, which lifts it): a test that creeps past
+# than SEA_TEST_MAX_SECONDS (default 180; the builder's full-set runs use SEA_MIOU_FULL=1, which lifts it): a test that creeps past
 # it fails HERE, by name, instead of taking the whole suite's evidence with it by timeout at the end of a round.  (Slowest test
 # of the suite: 53 s.  The cap was 75 s until a two-rank test that normally takes 21 s took 65 s as the FIRST process-spawning
-# test on a fresh box -- cold page cache for the children's `import torch` --: the margin is for the box, not for the code.)
-_MAX_S = float(os.environ.get("SEA_TEST_MAX_SECONDS", "0" if os.environ.get("SEA_MIOU_FULL") == "1" else "120"))
+# test on a fresh box -- cold page cache for the children's `import torch` --, and the 57 s test took 80 s on one lease: the
+# margin is for the box, not for the code.)
+_MAX_S = float(os.environ.get("SEA_TEST_MAX_SECONDS", "0" if os.environ.get("SEA_MIOU_FULL") == "1" else "180"))
 DURATIONS = {}
 
 

@@ -137,6 +137,7 @@ def model_gemm_roofline(N, model, x, ms_per_step):
     between two events, for 8192 x 1536 x 384).  Priced against the dense 16-bit MFMA peak: 2 G M K N flop x products (3 for
     fp16 x 2 / bf16 x 2: hi*hi', hi*mid', mid*hi') / time per launch."""
     orig, depth, rec, target, REPS = N.gemm_split, [0], {}, [None], 10
+    TIMED, MAX_EXTRA = 4, 2     # event pairs per call position (the MINIMUM is quoted); extra passes if a shape is unstable
 
     def hooked(A, Wp, *a, **k):
         if depth[0]:
@@ -156,47 +157,117 @@ def model_gemm_roofline(N, model, x, ms_per_step):
         return out
 
     flops = lambda k: k[0] * k[1] * k[2] * k[3]  # noqa: E731
+    samples = {}                # key -> [per pass: [ms of a single launch, per call position]]
+
+    def one_pass():
+        xg = x.clone().requires_grad_(True)
+        torch.autograd.grad(model(xg).float().square().mean(), xg)
+        torch.cuda.synchronize()
+
+    def harvest():
+        for k, v in rec.items():
+            samples.setdefault(k, []).append([a.elapsed_time(b) / r for a, b, r in v])
+        rec.clear()
+
+    def fold():
+        """per shape: ms per step from the minimum over the passes at every call position, and the same from the
+        second-smallest sample (one event pair around ten launches still catches a clock or host hiccup: a 2 x outlier of a
+        single pair went straight into round 5's line)"""
+        best, second = {}, {}
+        for k, per_pass in samples.items():
+            n = min(len(p) for p in per_pass)
+            cols = [sorted(p[i] for p in per_pass) for i in range(n)]
+            best[k] = (sum(c[0] for c in cols), n)
+            second[k] = sum(c[min(1, len(c) - 1)] for c in cols)
+        return best, second
+
     N.gemm_split = hooked
-    passes = 3
     try:
-        for i in range(passes):
-            xg = x.clone().requires_grad_(True)
-            torch.autograd.grad(model(xg).float().square().mean(), xg)
-            torch.cuda.synchronize()
-            if i == 0 and rec:
-                target[0] = max(rec, key=flops)
-                rec.clear()
+        one_pass()                                  # pass 1 finds the shapes (and warms them)
+        if rec:
+            target[0] = max(rec, key=flops)
+        rec.clear()
+        if target[0] is not None:
+            for _ in range(TIMED):
+                one_pass()
+                harvest()
+            for _ in range(MAX_EXTRA):              # a shape whose best figure is not confirmed by its second sample: sample again
+                best, second = fold()
+                if all(second[k] <= 1.3 * best[k][0] for k in best):
+                    break
+                one_pass()
+                harvest()
     finally:
         N.gemm_split = orig
-    if not rec:
+    if not samples:
         return None
-    passes -= 1
-    tot = {k: sum(a.elapsed_time(b) / r for a, b, r in v) for k, v in rec.items()}    # ms per single launch, summed over calls
+    best, second = fold()
+    tot = {k: v[0] for k, v in best.items()}        # ms per step of the shape (every call position at its minimum)
     peak = 2500.0   # dense bf16 / fp16 MFMA peak, TFLOP/s (MI355X_MICROARCH.md)
-    all_ms = sum(tot.values()) / passes
+    all_ms = sum(tot.values())
 
     def price(key):
         G, M, K, Nn, terms = key
-        n = len(rec[key])
+        n = best[key][1]
         prod = {22: 3, 2: 3, 3: 6, 1: 1}.get(terms, 1)
         flop = 2.0 * G * M * K * Nn * prod
         us = tot[key] / n * 1e3
         ach = flop / (us * 1e-6) / 1e12
         return {"kernel": f"sea_gemm_split {G} x ({M} x {K} x {Nn}), {_mode_name(terms)}", "bound": "mfma", "achieved": ach,
                 "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None, "flop_per_launch": flop,
-                "mfma_products": prod, "avg_launch_us": us, "launches_per_step": n / passes,
-                "ms_per_step": tot[key] / passes}
+                "mfma_products": prod, "avg_launch_us": us, "launches_per_step": n,
+                "ms_per_step": tot[key], "second_sample_over_min": second[key] / tot[key],
+                "event_pairs_per_call": len(samples[key])}
 
-    largest = target[0] if target[0] in rec else max(rec, key=flops)
+    largest = target[0] if target[0] in tot else max(tot, key=flops)
     busiest = max(tot, key=tot.get)                     # the shape with the most time per step (many small launches)
     out = price(largest)
+    unstable = sorted(f"{k[0]} x ({k[1]} x {k[2]} x {k[3]})" for k in tot if second[k] > 1.3 * tot[k])
     out.update({"most_time_per_step": price(busiest), "all_gemm_split_ms_per_step": all_ms,
                 "all_gemm_split_share_of_step": all_ms / ms_per_step,
+                "shapes_whose_second_sample_exceeds_1.3x_min": unstable,
                 "measured": "HIP events around every outermost gemm_split call in eager forward + input-gradient passes after the "
                             f"timed region; every call {REPS} x back to back per event pair (sustained load, no host gap "
-                            "inside the pair after the first launch; launches shorter than the ~25 us the host needs per eager call "
-                            "still read long: rocprofv3's per-kernel times under profiles/ are the reference for those)"})
+                            f"inside the pair after the first launch), {TIMED}+ pairs per call position, the MINIMUM quoted and "
+                            "checked against the second-smallest; launches shorter than the ~25 us the host needs per eager call "
+                            "still read long: rocprofv3's per-kernel times under profiles/ are the reference for those"})
     return out
+
+
+def strict_fp32_ms(A, N, run, model, x, y, eps, args, C, weights, barrier):
+    """ms per step of the SAME loop with operands that carry all 24 significant bits (bf16 x 3: the fp32 operands exactly, six
+    MFMA products; attention with three terms too), timed after the headline's region on a fresh run (its graph pair is
+    captured again: the cached pair's arithmetic signature no longer matches).  The shipped mode -- fp16 x 2, 22 bits,
+    error <= the fp32 GEMM's own -- is a judgment call; this is the figure to read it against."""
+    import semseg.models.convnext_upernet as M
+    run.release_graphs()
+    A.release_graph_cache(model)
+    old = (M.GEMM_TERMS, M.GEMM_TERMS_BWD, os.environ.get("SEA_ATTN_TERMS"), os.environ.get("SEA_ATTN_TERMS_BWD"))
+    K, W = args.strict_steps, 4
+    try:
+        M.GEMM_TERMS, M.GEMM_TERMS_BWD = 3, 3
+        os.environ["SEA_ATTN_TERMS"] = os.environ["SEA_ATTN_TERMS_BWD"] = "3"
+        r2 = A.ApgdRun(model, x, y, eps, max(W + K + 1, A.GRAPH_MIN_ITER), args.loss, "ce-avg", True, C, weights, x.clone(),
+                       fuse_upsample=True if args.fuse_upsample else (False if args.no_fuse_upsample else None))
+        r2.start()
+        for i in range(W):
+            r2.step(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(W, W + K):
+            r2.step(i)
+        barrier()
+        ms = (time.perf_counter() - t0) * 1e3 / K
+        r2.release_graphs()
+        return ms
+    finally:
+        M.GEMM_TERMS, M.GEMM_TERMS_BWD = old[0], old[1]
+        for k, v in (("SEA_ATTN_TERMS", old[2]), ("SEA_ATTN_TERMS_BWD", old[3])):
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        A.release_graph_cache(model)
 
 
 def _mode_name(terms):
@@ -270,6 +341,9 @@ def main():
                     help="skip the eager GEMM-timing passes after the timed region (profiling runs: they would land in the trace)")
     ap.add_argument("--sustain", type=int, default=300,
                     help="steps timed AFTER the K-step window for config.sustained_ms_per_step (0 = skip)")
+    ap.add_argument("--strict-steps", type=int, default=20,
+                    help="steps timed AFTER everything else with exact fp32 operands (three bf16 terms) for "
+                         "config.strict_fp32_ms_per_step (0 = skip)")
     ap.add_argument("--fuse-upsample", action="store_true",
                     help="force K2u (loss fused with the model's final bilinear upsample); default: the library's "
                          "heuristic (unfused unless the full-resolution logits + gradient exceed 24 GB)")
@@ -365,6 +439,8 @@ def main():
             sustained = float(mine.item())
 
     k2_ms = (sum(a.elapsed_time(b) for a, b in run.k2_events) / max(len(run.k2_events), 1)) if run.k2_events else float("nan")
+    hip_graph = bool(run.graphs is not None)
+    strict = strict_fp32_ms(A, N, run, model, x, y, eps, args, C, weights, barrier) if args.strict_steps > 0 else None
     kname = ("loss_upsampled_kernel (K2u)" if run.fused else
              f"{'loss_nchw_split' if C in (150, 151) else 'loss_nchw_reg'}<C={C}> (K2 fused loss fwd+bwd)")
     algo = k2_algorithmic_bytes(B, C, 512 * 512)
@@ -415,8 +491,12 @@ def main():
                             f"eps={args.eps:g}/255, loss {args.loss}, track ce-avg (BASELINE configs[1] loop body)",
                 "batch_per_gpu": B, "global_batch": world * B, "sharding": f"images x{world}, no in-loop collective",
                 "batch_steps_per_s": world * K / dt, "host_enqueue_ms_per_step": t_enqueue * 1e3 / K,
-                "hip_graph": bool(run.graphs is not None),
+                "hip_graph": hip_graph,
                 "sustained_ms_per_step": sustained, "sustained_steps": S,
+                # the same loop with operands that carry all 24 bits of fp32 (three bf16 terms, six MFMA products, forward
+                # and input gradient; attention likewise): what the headline's 22-bit operands buy, measured in this run
+                "strict_fp32_ms_per_step": strict, "strict_fp32_steps": args.strict_steps if strict is not None else 0,
+                "strict_fp32_mode": "SEA_GEMM_TERMS=3 SEA_GEMM_TERMS_BWD=3 SEA_ATTN_TERMS=3 SEA_ATTN_TERMS_BWD=3, after the timed region",
                 "gemm": ("sea_gemm_split: forward products " + _mode_name(GEMM_TERMS) + ", input-gradient products "
                          + _mode_name(_bwd_terms(GEMM_TERMS)) + ", fp32 accumulate; power-of-two scales per row (forward: analytic "
                          + "bounds / Winograd tile maxima; gradient: exact row maxima / Winograd tile maxima / row bounds carried "

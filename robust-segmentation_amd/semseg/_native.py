@@ -895,6 +895,7 @@ class PackedWeight:
         """this weight as a batch of S packed (N x K/S) matrices, one per K slice"""
         if S not in self.slices:
             self.slices[S] = self._slices_of(S)
+            CACHE_EPOCH[0] += 1          # a new device address that a captured graph cannot know about
         return self.slices[S]
 
     def refresh_from(self, new) -> bool:

@@ -369,6 +369,40 @@ def _weights_key(model):
     return hash(tuple((id(t), t.data_ptr(), t._version) for t in list(model.parameters()) + list(model.buffers())))
 
 
+def _arith_signature(model):
+    """Everything process-global that a captured forward / backward bakes in besides addresses and weights: the arithmetic
+    switches of the model modules (every UPPER-CASE scalar global of semseg.models.*: GEMM_TERMS, GEMM_TERMS_BWD,
+    WINOGRAD_TILE, WINOGRAD_MIN_PIXELS, USE_*, FUSE_MLP ...; the in-process override of the GEMM terms), the attention
+    arithmetic (read per call from the environment), the library's K-loop pipeline and MFMA shape, the autocast state and
+    ``model.training``.  A cached pair whose signature differs is captured again instead of replaying the old arithmetic."""
+    import sys
+    sig = [bool(getattr(model, "training", False)), torch.is_autocast_enabled(),
+           str(torch.get_autocast_gpu_dtype()) if torch.is_autocast_enabled() else None,
+           N.attn_terms_fwd(), N.attn_terms_bwd(), int(N.lib().sea_gemm_split_pipeline(-1)),
+           int(N.lib().sea_gemm_split_mfma_shape(0)), bool(N.AMAX_FROM_PRODUCERS)]
+    for name in sorted(sys.modules):
+        if name.startswith("semseg.models."):
+            mod = sys.modules[name]
+            sig.append((name, tuple((k, v) for k, v in sorted(vars(mod).items())
+                                    if k.isupper() and isinstance(v, (bool, int, float, str)))))
+            if hasattr(mod, "_TERMS_OVERRIDE"):
+                sig.append(tuple(mod._TERMS_OVERRIDE))
+    return tuple(sig)
+
+
+class _Volatile:
+    """Marker in a model's slot table: the weights behind this shape changed between two runs (a training loop such as
+    tools/train_rob_seg.py with ATTACK=apgd, whose every outer step moves the parameters' versions).  Such a run gets NO
+    slot -- it captures its own pair and frees it with its activation pool on return, as before round 5 -- and a slot is
+    attached again only once two consecutive runs saw the same weights."""
+
+    def __init__(self, weights_key):
+        self.weights_key = weights_key
+
+
+GRAPH_SLOTS_PER_MODEL = 2       # shapes kept per model (an evaluation has at most a full and a ragged last batch)
+
+
 def _graph_slot(model, x, num_classes, n_iter):
     if not (GRAPH_CACHE and isinstance(model, torch.nn.Module)):
         return None
@@ -378,13 +412,35 @@ def _graph_slot(model, x, num_classes, n_iter):
         return None
     key = (tuple(x.shape), x.dtype, x.device.index, num_classes)
     wkey = _weights_key(model)
-    slot = slots.get(key)
-    if slot is not None and (slot.weights_key != wkey or slot.cap_iter < n_iter):
-        slot = None                 # other weights (a training step, a loaded checkpoint) or a longer run: start over
-    if slot is None:
-        slot = slots[key] = _GraphSlot(x, num_classes, max(GRAPH_SLOT_MIN_ITERS, n_iter), wkey)
-    if slot.busy:
+    slot = slots.pop(key, None)             # (re-inserted below: the dict keeps the most recently used shape last)
+    if isinstance(slot, _Volatile):
+        if slot.weights_key != wkey:        # still moving: no slot, no several GB parked on the model
+            slot.weights_key = wkey
+            slots[key] = slot
+            return None
+        slot = None                         # the weights held still for two runs: cache again
+    elif slot is not None and slot.weights_key != wkey:
+        # other weights (a training step, a loaded checkpoint): free the stale pair and its pool BEFORE anything new is
+        # allocated, and let this run capture for itself
+        slot.drop_graphs()
+        slots[key] = _Volatile(wkey)
         return None
+    elif slot is not None and slot.busy:
+        slots[key] = slot
+        return None                         # a nested run gets its own buffers
+    elif slot is not None and slot.cap_iter < n_iter:
+        slot.drop_graphs()                  # a longer run than the tables were sized for: start over
+        slot = None
+    if slot is None:
+        live = [k for k, v in slots.items() if isinstance(v, _GraphSlot)]
+        while len(live) >= GRAPH_SLOTS_PER_MODEL:           # least recently used shape first
+            old = slots.pop(live.pop(0))
+            if old.busy:                                    # (its run is still going: leave it alone, take no slot)
+                slots[key] = _Volatile(wkey)
+                return None
+            old.drop_graphs()
+        slot = _GraphSlot(x, num_classes, max(GRAPH_SLOT_MIN_ITERS, n_iter), wkey)
+    slots[key] = slot
     return slot
 
 
@@ -392,7 +448,8 @@ def release_graph_cache(model=None):
     """drop the cached graph pairs (and the several GB of activations their pools hold) of ``model``, or of every model"""
     for m in ([model] if model is not None else list(_GRAPH_SLOTS.keys())):
         for slot in _GRAPH_SLOTS.pop(m, {}).values():
-            slot.drop_graphs()
+            if isinstance(slot, _GraphSlot):
+                slot.drop_graphs()
 
 
 class ApgdRun:
@@ -638,8 +695,9 @@ class ApgdRun:
             sl.g_xin, sl.g_logits = self._g_xin, self._g_logits
 
     def _graph_sig(self):
-        """what a captured pair bakes in besides addresses: K7's early-stop flag and where it finds K2's sums"""
-        return (bool(self.early_stop), bool(self.defer))
+        """what a captured pair bakes in besides addresses and weights: K7's early-stop flag, where it finds K2's sums, and
+        the process-global arithmetic state of the model's forward / backward (``_arith_signature``)"""
+        return (bool(self.early_stop), bool(self.defer), _arith_signature(self.model))
 
     def _step_graph(self, i: int):
         if self.graphs is not None and self.slot is not None and i == self._first_graph_step:
@@ -709,6 +767,14 @@ def apgd_train(model, x, y, norm, eps, n_iter=10, use_rs=False, loss="ce", verbo
         n_ign = int(run.n_ignored.sum())
         if n_ign > 0:
             logger.log(f"{n_ign / y.numel():.2%} pixels are masked out.")
+    try:
+        return _apgd_drive(run, y, n_iter, verbose, logger, early_stop, poll_every, num_classes, return_pred)
+    finally:
+        run.release_graphs()            # (also when a step raises: the slot must not stay busy)
+
+
+def _apgd_drive(run, y, n_iter, verbose, logger, early_stop, poll_every, num_classes, return_pred):
+    """the loop of ``apgd_train`` (reference lines 342-569) over a constructed run"""
     run.start()
     if verbose:
         m_acc, a_acc, m_iou = compute_iou_acc(run.pred_best.long(), y, num_classes)
@@ -739,7 +805,6 @@ def apgd_train(model, x, y, norm, eps, n_iter=10, use_rs=False, loss="ce", verbo
     out = run.result()
     if return_pred:
         out = out + ((run.pred_best.clone() if run.slot is not None else run.pred_best),)
-    run.release_graphs()
     return out
 
 

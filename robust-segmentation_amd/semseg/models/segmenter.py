@@ -54,7 +54,9 @@ class _AttentionHip(torch.autograd.Function):
     @_fp32_fwd
     def forward(ctx, qkv, scale, train=False):
         from .. import _native as N
-        out, lse = N.attention_qkv(qkv, scale)
+        # training: three bf16 terms per operand (the fp32 operands exactly), forward AND backward -- the backward consumes the
+        # forward's out / lse; attack (frozen qkv projection): N.attn_terms_fwd(), fp16 x 2 by default
+        out, lse = N.attention_qkv(qkv, scale, terms=3 if train else None)
         ctx.save_for_backward(qkv, out, lse)
         ctx.scale, ctx.train = scale, train
         return out

@@ -106,7 +106,11 @@ class _PgdSlot:
 
 
 def _param_key(model):
-    return hash(tuple((id(t), t.data_ptr()) for t in list(model.parameters()) + list(model.buffers())))
+    """what a captured inner-PGD graph is valid for besides `_native.CACHE_EPOCH`: the parameter / buffer tensors (identity and
+    address; their CONTENTS may change, the caches refresh in place), which of them require a gradient (a frozen layer takes
+    other kernels), and the process-global arithmetic state incl. ``model.training`` (attacker._arith_signature)"""
+    ts = list(model.parameters()) + list(model.buffers())
+    return hash((tuple((id(t), t.data_ptr(), bool(t.requires_grad)) for t in ts), _A._arith_signature(model)))
 
 
 def release_pgd_graphs(model=None):

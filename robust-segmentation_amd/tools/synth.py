@@ -97,6 +97,7 @@ def sea_evaluate(model, images, labels, weights, eps: float, n_iter: int, batch:
             pl = p.long()
             pl[y == -1] = -1
             preds[a, idx] = pl.cpu()
+    attacker.release_graph_cache(model)      # the captured pair and its activation pool (several GB) do not outlive the evaluation
     if tables is not None:
         tables.update(inter=inter, union=union, valid=valid)
     worst, _, _ = worst_acc_from_counts(inter.sum(-1), valid)

@@ -79,9 +79,15 @@ def build_attack(train_cfg):
         else:
             atk = Pgd_Attack(eps=eps, alpha=1e-2, num_iter=n, los=los)
         return lambda model, img, lbl: atk.adv_attack(model, img, lbl)[0]
-    return lambda model, img, lbl: attacker.apgd_train(model, img, lbl, norm="Linf", eps=eps, n_iter=n, use_rs=True,
-                                                       loss="ce-avg", track_loss=None,
-                                                       num_classes=int(train_cfg.get("N_CLS", 21)))[0]  # x_best, as the reference (train_rob_seg.py:336)
+    def apgd(model, img, lbl):
+        try:
+            return attacker.apgd_train(model, img, lbl, norm="Linf", eps=eps, n_iter=n, use_rs=True, loss="ce-avg",
+                                       track_loss=None, num_classes=int(train_cfg.get("N_CLS", 21)))[0]  # x_best, as the reference (train_rob_seg.py:336)
+        finally:
+            # the weights move every outer step: a captured pair is good for this call only, and its activation pool
+            # (several GB) must not sit on the model through the training forward / backward
+            attacker.release_graph_cache(model)
+    return apgd
 
 
 def _main(argv=None):

@@ -483,6 +483,35 @@ int sea_gemm_split_fused(const float* A, int64_t lda, const void* Wp, float* C, 
 int sea_gemm_split(const float* A, int64_t lda, const void* Wp, float* C, int64_t ldc, const float* bias, int relu, int M,
                    int N, int K, int terms, int batch, int64_t strideA, int64_t strideW_bytes, int64_t strideC,
                    void* stream);
+/* ------------------------------------------------------------------------------------------------
+ * M8f  the MLP of a ConvNeXt block, y = res + W2 GELU(W1 x + b1) + b2 (semseg/models/backbones/convnext_orig.py:77-79:
+ *      pwconv1 -> act -> pwconv2 with the layer scale folded into W2; reference autograd for the input gradient), as ONE
+ *      kernel per direction.  Replaces, bit for bit, the pair of sea_gemm_split_fused launches (a_gelu / a_gelu_grad_of
+ *      prologues), the residual add and -- backward -- the sea_absmax_bits(rows_per_word = 1) pass: a wave owns 32 rows for
+ *      the whole MLP, the 4C-wide hidden tensor lives in accumulators and operand registers only (it is the HBM traffic that
+ *      bounds the two-GEMM form at C = 96 / 192).  The backward recomputes t = W1 x + b1: the forward saves nothing but x.
+ *   x, res, y / g, dx: (M, C) fp32 rows (row strides in elements, % 4 == 0, 16-byte aligned); H = 4 C; C in {96, 192}
+ *     (sea_mlp_fused_supported).  W1p = sea_gemm_split_pack(w1: N = H, K = C, terms 22), W2p = pack(w2: N = C, K = H);
+ *     backward: W2tp = pack(w2, trans = 1: N = H, K = C), W1tp = pack(w1, trans = 1: N = C, K = H).
+ *   amax_x / amax_h: ONE device word each, float bits of an upper bound of max|x| / max|GELU(W1 x + b1)| (the analytic
+ *     bounds of sea_gemm_split_f16's comment); amax_mul_dev: ONE float, rowmax|g[r]| * it bounds row r of (g W2) GELU'
+ *     (SeaGemmEpilogue.a_amax_mul_dev).  b2 / res may be NULL. */
+int sea_mlp_fused_supported(int C, int H);
+/* test probe: out[0], out[1] (two pre-zeroed 64-bit device words) += the number of fp32 bit patterns for which the branch-free
+ * GELU / GELU' evaluation inside the fused kernels differs from the one of sea_gemm_split's prologues (must stay 0, 0) */
+int sea_probe_gelu_mismatches(unsigned long long* out, void* stream);
+/* diagnostic build of the C = 96 fused kernels with s_memtime stamps around the segments of a loop iteration
+ * (devtools/mlp_fused_stamps.py); dbg: 8 uint64 per wave.  W2p: pack(w2) forward, pack(w2, trans) backward. */
+int sea_mlp_fused_stamps(int bwd, const float* g, int64_t ldg, const float* x, int64_t ldx, const void* W1p, const float* b1,
+                         const void* W2p, const void* W1tp, const float* b2, const float* res, float* y, int M, int C,
+                         const uint32_t* amax_x, const uint32_t* amax_h, const float* amax_mul_dev, unsigned long long* dbg,
+                         void* stream);
+int sea_mlp_fused_fwd(const float* x, int64_t ldx, const void* W1p, const float* b1, const void* W2p, const float* b2,
+                      const float* res, int64_t ldres, float* y, int64_t ldy, int M, int C, int H, const uint32_t* amax_x,
+                      const uint32_t* amax_h, void* stream);
+int sea_mlp_fused_bwd(const float* g, int64_t ldg, const float* x, int64_t ldx, const void* W1p, const float* b1,
+                      const void* W2tp, const void* W1tp, float* dx, int64_t lddx, int M, int C, int H,
+                      const uint32_t* amax_x, const float* amax_mul_dev, void* stream);
 /* Tuning knob of the sea_gemm_split* kernels: MFMA fragment shape, 32 (v_mfma_f32_32x32x16_{f16,bf16}; default) or 16
  * (v_mfma_f32_16x16x32_*; also env SEA_GEMM_SHAPE=16).  Any other argument only queries.  Returns the previous shape. */
 int sea_gemm_split_mfma_shape(int shape);

@@ -95,6 +95,11 @@ _SIGS = {
     "sea_gemm_split_packed_bytes": (_i64, [_i, _i, _i]),
     "sea_gemm_split_pack": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp]),
     "sea_gemm_split": (_i, [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _vp]),
+    "sea_mlp_fused_supported": (_i, [_i, _i]),
+    "sea_probe_gelu_mismatches": (_i, [_vp, _vp]),
+    "sea_mlp_fused_stamps": (_i, [_i, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "sea_mlp_fused_fwd": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp, _vp, _vp]),
+    "sea_mlp_fused_bwd": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp]),
     "sea_gemm_split_mfma_shape": (_i, [_i]),
     "sea_gemm_split_pipeline": (_i, [_i]),
     "sea_probe_stream_copy": (_i, [_vp, _vp, _sz, _i, _vp]),
@@ -929,6 +934,63 @@ def gemm_split_pack(W, trans: bool = False, terms: int = 3) -> PackedWeight:
         _check(L.sea_gemm_split_pack(_p(Wb[g]), Wb.stride(1), int(trans), N, K, terms, _p(out[g]), _stream()),
                "sea_gemm_split_pack")
     return PackedWeight(out, N, K, terms, G, src=(W.detach(), trans) if (W.dim() == 2 and W.is_contiguous()) else None)
+
+
+# ------------------------------------------------------------------------------------------------ M8f
+USE_MLP_FUSED = os.environ.get("SEA_MLP_FUSED", "1") != "0"
+
+
+def mlp_fused_ok(C: int, H: int) -> bool:
+    """the fused-MLP kernels exist for this block width (ConvNeXt stages of 96 / 192 channels, hidden = 4 C)"""
+    return bool(USE_MLP_FUSED and lib().sea_mlp_fused_supported(int(C), int(H)))
+
+
+def _mlp_rows(t, C, what):
+    if t.dtype != torch.float32 or t.dim() != 2 or t.shape[1] != C or t.stride(1) != 1 or t.stride(0) % 4 or t.data_ptr() % 16:
+        raise SeaNativeError(f"mlp_fused: {what} must be float32 (M, {C}) rows, 16-byte aligned, row stride % 4 == 0")
+
+
+def mlp_fused_forward(x2, W1p: PackedWeight, b1, W2p: PackedWeight, b2, res, amax_x, amax_h, out=None):
+    """out = res + W2 GELU(W1 x2 + b1) + b2 in ONE kernel (sea_mlp_fused_fwd): the hidden tensor never leaves the CU.  W1p / W2p:
+    the fp16 x 2 packs (terms 22) of w1 (H x C) and w2 (C x H); amax_x / amax_h: one int32 device word each, float bits of a
+    bound of max|x2| and of max|GELU(W1 x2 + b1)|.  Bit for bit the two gemm_split launches (a_gelu prologue) plus the add."""
+    _dev(x2, b1, b2, res, out, amax_x, amax_h)
+    M, Cc = x2.shape
+    H = W1p.N
+    if (W1p.terms, W2p.terms, W1p.K, W2p.N, W2p.K, W1p.batch, W2p.batch) != (22, 22, Cc, Cc, H, 1, 1):
+        raise SeaNativeError("mlp_fused_forward: fp16 x 2 packs of w1 (H x C) and w2 (C x H) expected")
+    _mlp_rows(x2, Cc, "x")
+    if res is not None:
+        _mlp_rows(res, Cc, "res")
+    if out is None:
+        out = torch.empty(M, Cc, dtype=torch.float32, device=x2.device)
+    _mlp_rows(out, Cc, "out")
+    _check(lib().sea_mlp_fused_fwd(_p(x2), x2.stride(0), _p(W1p.data), _p(b1), _p(W2p.data), _p(b2), _p(res),
+                                   res.stride(0) if res is not None else 0, _p(out), out.stride(0), M, Cc, H, _p(amax_x),
+                                   _p(amax_h), _stream()), "sea_mlp_fused_fwd")
+    return out
+
+
+def mlp_fused_backward(g2, x2, W1p: PackedWeight, b1, W2tp: PackedWeight, W1tp: PackedWeight, amax_x, amax_mul, out=None):
+    """input gradient of ``mlp_fused_forward`` w.r.t. x2 (sea_mlp_fused_bwd): t = W1 x2 + b1 is recomputed, u = g2 W2 and
+    dx = (u GELU'(t)) W1 follow in the same kernel.  W2tp / W1tp: the packs of w2 and w1 with trans=True (the operands of the
+    two input-gradient products); amax_mul: ONE float32 on the device, rowmax|g2[r]| * amax_mul bounds row r of u GELU'(t).
+    Bit for bit the rowmax pass + the two gemm_split launches (a_gelu_grad_of prologue) of the unfused backward."""
+    _dev(g2, x2, b1, out, amax_x, amax_mul)
+    M, Cc = x2.shape
+    H = W1p.N
+    if ((W1p.terms, W2tp.terms, W1tp.terms) != (22, 22, 22) or (W1p.K, W2tp.N, W2tp.K, W1tp.N, W1tp.K) != (Cc, H, Cc, Cc, H)
+            or amax_mul.dtype != torch.float32 or amax_mul.numel() != 1):
+        raise SeaNativeError("mlp_fused_backward: fp16 x 2 packs of w1, w2^T, w1^T and one float32 amax_mul expected")
+    _mlp_rows(x2, Cc, "x")
+    _mlp_rows(g2, Cc, "g")
+    if out is None:
+        out = torch.empty(M, Cc, dtype=torch.float32, device=x2.device)
+    _mlp_rows(out, Cc, "out")
+    _check(lib().sea_mlp_fused_bwd(_p(g2), g2.stride(0), _p(x2), x2.stride(0), _p(W1p.data), _p(b1), _p(W2tp.data),
+                                   _p(W1tp.data), _p(out), out.stride(0), M, Cc, H, _p(amax_x), _p(amax_mul), _stream()),
+           "sea_mlp_fused_bwd")
+    return out
 
 
 class AmaxPool:

@@ -466,9 +466,24 @@ class _FrozenMlp(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1])
         if terms != 22:
             a1 = a2 = None
-        t = torch.empty(x2.shape[0], w1.shape[0], dtype=torch.float32, device=x.device)
         fuse, nb = int(FUSE_MLP), (x.shape[0] if x.dim() > 2 else 1)
         r2 = None if res is None else res.reshape(-1, res.shape[-1])
+        ctx.w, ctx.b1, ctx.caches, ctx.shape, ctx.terms, ctx.has_res = (w1, w2), b1, caches, x.shape, terms, res is not None
+        ctx.fuse, ctx.a1 = fuse, a1
+        # M8f (csrc/mlp_fused.hip): both projections, GELU and the residual in ONE kernel whose hidden tile never leaves the CU
+        # -- where the two-GEMM form is bound by the 4C-wide tensor's HBM round trips (C = 96 / 192).  Same bits as the pair
+        # below; only x2 is kept for the backward, which recomputes t in its own fused kernel.
+        rows_ok = lambda t: t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0   # noqa: E731
+        if (terms == 22 and fuse & 16 and a1 is not None and a2 is not None and a1.numel() == 1 and a2.numel() == 1
+                and b1 is not None and N.mlp_fused_ok(w2.shape[0], w1.shape[0]) and rows_ok(x2)
+                and (r2 is None or rows_ok(r2))):
+            y = N.mlp_fused_forward(x2, _packed(w1, caches[0], "lin_fwd", False, terms), b1,
+                                    _packed(w2, caches[1], "lin_fwd", False, terms), b2, r2, a1, a2)
+            ctx.kernel_fused = True
+            ctx.save_for_backward(x2)
+            return y.view(x.shape)
+        ctx.kernel_fused = False
+        t = torch.empty(x2.shape[0], w1.shape[0], dtype=torch.float32, device=x.device)
         pro = bool(fuse & 16) and -(-w2.shape[0] // 128) <= FUSE_PROLOGUE_MAX_NBLOCKS and not fuse & 1
         if pro:
             N.gemm_split(x2, _packed(w1, caches[0], "lin_fwd", False, terms), bias=b1, out=t, amax=a1, groups=nb)
@@ -487,9 +502,7 @@ class _FrozenMlp(torch.autograd.Function):
                          a_gelu=pro, addend=r2 if add_in else None)
         if r2 is not None and not add_in:
             y += r2
-        ctx.fuse = fuse
         ctx.save_for_backward(t)
-        ctx.w, ctx.caches, ctx.shape, ctx.terms, ctx.has_res = (w1, w2), caches, x.shape, terms, res is not None
         return y.view(x.shape)
 
     @staticmethod
@@ -502,6 +515,15 @@ class _FrozenMlp(torch.autograd.Function):
         if not g2.is_contiguous():
             g2 = g2.contiguous()
         nb = ctx.shape[0] if len(ctx.shape) > 2 else 1
+        if ctx.kernel_fused:
+            x2 = t                       # (the fused forward saved its INPUT: t is recomputed)
+            p1f = _packed(ctx.w[0], ctx.caches[0], "lin_fwd", False, ctx.terms)
+            if terms == 22 and g2.data_ptr() % 16 == 0:
+                gx = N.mlp_fused_backward(g2, x2, p1f, ctx.b1, _packed(ctx.w[1], ctx.caches[1], "lin_bwd", True, terms),
+                                          _packed(ctx.w[0], ctx.caches[0], "lin_bwd", True, terms), ctx.a1,
+                                          _l1_bound(ctx.w[1], ctx.caches[1], dim=0, factor=1.13))
+                return gx.view(ctx.shape), None, None, None, None, (g if ctx.has_res else None), None, None, None
+            t = N.gemm_split(x2, p1f, bias=ctx.b1, amax=ctx.a1, groups=nb)      # another backward arithmetic: the pair below
         p2, p1 = (_packed(ctx.w[1], ctx.caches[1], "lin_bwd", True, terms), _packed(ctx.w[0], ctx.caches[0], "lin_bwd", True, terms))
         # fp16 x 2: ONE pass for the per-row maxima of g; the second product's operand u = g W2 (times GELU' <= 1.13) is
         # bounded row by row through the first: |u[r][n]| <= rowmax(g[r]) * max_n ||W2[n]||_1  (no pass over the 4C-wide u)

@@ -156,7 +156,25 @@ def model_gemm_roofline(N, model, x, ms_per_step):
         rec.setdefault(key, []).append((e0, e1, reps))
         return out
 
-    flops = lambda k: k[0] * k[1] * k[2] * k[3]  # noqa: E731
+    # the fused MLP kernels (M8f: both projections of a ConvNeXt block in one launch) are M8 work too: timed the same way and
+    # counted in all_gemm_split_ms_per_step (key: ("mlp_fwd" | "mlp_bwd", M, C, H, 22))
+    orig_mf, orig_mb = N.mlp_fused_forward, N.mlp_fused_backward
+
+    def hooked_mlp(tag, fn):
+        def run(*a, **k):
+            x2, W1p = (a[0], a[1]) if tag == "mlp_fwd" else (a[1], a[2])
+            key = (tag, x2.shape[0], x2.shape[1], W1p.N, 22)
+            reps = REPS if target[0] is not None else 1
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                out = fn(*a, **k)
+            e1.record()
+            rec.setdefault(key, []).append((e0, e1, reps))
+            return out
+        return run
+
+    flops = lambda k: 0 if isinstance(k[0], str) else k[0] * k[1] * k[2] * k[3]  # noqa: E731
     samples = {}                # key -> [per pass: [ms of a single launch, per call position]]
 
     def one_pass():
@@ -182,6 +200,7 @@ def model_gemm_roofline(N, model, x, ms_per_step):
         return best, second
 
     N.gemm_split = hooked
+    N.mlp_fused_forward, N.mlp_fused_backward = hooked_mlp("mlp_fwd", orig_mf), hooked_mlp("mlp_bwd", orig_mb)
     try:
         one_pass()                                  # pass 1 finds the shapes (and warms them)
         if rec:
@@ -199,6 +218,7 @@ def model_gemm_roofline(N, model, x, ms_per_step):
                 harvest()
     finally:
         N.gemm_split = orig
+        N.mlp_fused_forward, N.mlp_fused_backward = orig_mf, orig_mb
     if not samples:
         return None
     best, second = fold()
@@ -210,6 +230,14 @@ def model_gemm_roofline(N, model, x, ms_per_step):
         G, M, K, Nn, terms = key
         n = best[key][1]
         prod = {22: 3, 2: 3, 3: 6, 1: 1}.get(terms, 1)
+        if isinstance(G, str):      # fused MLP: two (forward) / three (backward: t is recomputed) M x C x H products in one launch
+            flop = 2.0 * M * K * Nn * prod * (2 if G == "mlp_fwd" else 3)
+            us = tot[key] / n * 1e3
+            ach = flop / (us * 1e-6) / 1e12
+            return {"kernel": f"sea_mlp_fused_{G[4:]} M={M} C={K} H={Nn}, {_mode_name(terms)}", "bound": "mfma / valu", "achieved": ach,
+                    "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None, "flop_per_launch": flop,
+                    "mfma_products": prod, "avg_launch_us": us, "launches_per_step": n, "ms_per_step": tot[key],
+                    "second_sample_over_min": second[key] / tot[key], "event_pairs_per_call": len(samples[key])}
         flop = 2.0 * G * M * K * Nn * prod
         us = tot[key] / n * 1e3
         ach = flop / (us * 1e-6) / 1e12
@@ -220,10 +248,15 @@ def model_gemm_roofline(N, model, x, ms_per_step):
                 "event_pairs_per_call": len(samples[key])}
 
     largest = target[0] if target[0] in tot else max(tot, key=flops)
+    if isinstance(largest[0], str):
+        largest = max((k for k in tot if not isinstance(k[0], str)), key=flops)
     busiest = max(tot, key=tot.get)                     # the shape with the most time per step (many small launches)
     out = price(largest)
     unstable = sorted(f"{k[0]} x ({k[1]} x {k[2]} x {k[3]})" for k in tot if second[k] > 1.3 * tot[k])
+    mlp_ms = sum(v for k, v in tot.items() if isinstance(k[0], str))
     out.update({"most_time_per_step": price(busiest), "all_gemm_split_ms_per_step": all_ms,
+                "of_which_fused_mlp_ms_per_step": mlp_ms,
+                "fused_mlp": [price(k) for k in sorted(tot, key=str) if isinstance(k[0], str)],
                 "all_gemm_split_share_of_step": all_ms / ms_per_step,
                 "shapes_whose_second_sample_exceeds_1.3x_min": unstable,
                 "measured": "HIP events around every outermost gemm_split call in eager forward + input-gradient passes after the "

@@ -63,6 +63,14 @@ int sea_apgd_linf_step(const float* x, const float* x_adv, const float* x_old, c
                        int64_t n_per_img, void* stream);
 
 /* K5a random start: out = clip(x + eps*(2u-1), 0, 1).          semseg/attacker.py:293-294, 308 */
+/* K1' -- the L2 branch of apgd_train (semseg/attacker.py:412-436; per-image norm = autoattack.other_utils.L2_norm, attacker.py:6):
+ * normalised gradient step, projection onto the eps-ball (L2) around x and [0, 1], momentum combination, projection again.
+ * Four streaming passes that recompute the element-wise chain; the three per-image norms are sums of per-block partials in a
+ * fixed order (double), no atomics.  workspace: sea_apgd_l2_workspace_bytes(B) bytes, 8-byte aligned.  No shipped entry point
+ * of the reference reaches this branch: it completes the drop-in surface. */
+int64_t sea_apgd_l2_workspace_bytes(int B);
+int sea_apgd_l2_step(const float* x, const float* x_adv, const float* x_old, const float* grad, const float* step_b, float eps,
+                     float a, float* out, void* workspace, int B, int64_t n_per_img, void* stream);
 int sea_linf_random_start(const float* x, const float* u, float eps, float* out, int64_t n,
                           void* stream);
 /* K5b stage re-projection: out = clip(x + clip(z-x,-eps,eps), 0, 1). semseg/attacker.py:683-690 */

@@ -54,6 +54,28 @@ def apgd_linf_step(x, x_adv, x_old, grad, step, eps: float, a: float) -> torch.T
     return _box(z, x, eps)
 
 
+def l2_norm(t: torch.Tensor) -> torch.Tensor:
+    """per-image L2 norm, kept broadcastable: autoattack.other_utils.L2_norm(t, keepdim=True) (autoattack@a3922004:
+    ``(x ** 2).view(x.shape[0], -1).sum(-1).sqrt()``), the helper semseg/attacker.py:6 imports"""
+    return (t ** 2).reshape(t.shape[0], -1).sum(-1).sqrt().view(-1, *[1] * (t.dim() - 1))
+
+
+def apgd_l2_step(x, x_adv, x_old, grad, step, eps: float, a: float) -> torch.Tensor:
+    """One APGD L2 update with momentum (semseg/attacker.py:412-436, 456): a normalised gradient step, projection onto
+    the eps-ball around x and [0, 1], the momentum combination, projection again."""
+    step = step.view(-1, 1, 1, 1)
+    g2 = x_adv - x_old
+
+    def project(z):
+        d = z - x
+        n = l2_norm(d)
+        return torch.clamp(x + d / (n + 1e-12) * torch.min(eps * torch.ones_like(x), n), 0.0, 1.0)
+
+    z = project(x_adv + step * grad / (l2_norm(grad) + 1e-12))
+    z = x_adv + (z - x_adv) * a + g2 * (1 - a)
+    return project(z)
+
+
 def linf_random_start(x, u, eps: float) -> torch.Tensor:
     """clip(x + eps*(2u-1), 0, 1) with u ~ U[0,1) supplied by the caller (semseg/attacker.py:293-294)."""
     t = 2 * u - 1
@@ -318,19 +340,22 @@ def _model_logits_and_grad(model, x_adv, y, weights, mode, want_grad=True):
 
 def apgd_train(model, x, y, norm="Linf", eps=8.0 / 255, n_iter=10, use_rs=False, loss="mask-ce-avg",
                early_stop=False, track_loss=None, x_init=None, weights=None, noise=None, trace=None):
-    """One APGD run, L-inf only (semseg/attacker.py:260-571).
+    """One APGD run, L-inf or L2 (semseg/attacker.py:260-571; the L1 branch, lines 437-454 and 553-566,
+    is not restated: no shipped entry point reaches it).  The reference has a random start for L-inf only
+    (lines 291-294): ``use_rs`` with L2 needs ``x_init``, as there.
 
     ``noise`` replaces ``torch.rand_like(x)`` (line 293) so device and CPU runs can share it; when
     None and use_rs, the global torch CPU generator is consumed exactly like the reference.
     ``trace`` (optional dict) receives loss_steps / step sizes / acc per step for the tests.
     Returns (x_best, acc, loss_best, x_best_adv).
     """
-    assert norm == "Linf"
+    assert norm in ("Linf", "L2")
     assert not model.training
+    assert norm == "Linf" or not use_rs or x_init is not None
     mode = MODE_BY_NAME[loss]
     tmode = MODE_BY_NAME[track_loss] if track_loss is not None else mode
     B = x.shape[0]
-    if not use_rs:
+    if not use_rs or norm != "Linf":
         x_adv = x.clone()
     else:
         u = torch.rand_like(x) if noise is None else noise
@@ -357,7 +382,7 @@ def apgd_train(model, x, y, norm="Linf", eps=8.0 / 255, n_iter=10, use_rs=False,
 
     for i in range(n_iter):
         a = 0.75 if i > 0 else 1.0
-        x_new = apgd_linf_step(x, x_adv, x_old, grad, step, eps, a)
+        x_new = (apgd_linf_step if norm == "Linf" else apgd_l2_step)(x, x_adv, x_old, grad, step, eps, a)
         x_old = x_adv
         x_adv = x_new
         want = i < n_iter - 1

@@ -26,6 +26,7 @@ ARCH = "gfx950"
 # float32 multiply/add ops bit for bit.
 SOURCES = [
     ("linf_kernels.hip", ["-ffp-contract=off"]),
+    ("l2_kernels.hip", ["-ffp-contract=off"]),
     ("apgd_control.hip", ["-ffp-contract=off"]),
     ("loss_kernels.hip", []),
     ("loss_stream.hip", []),

@@ -27,6 +27,8 @@ _SIGS = {
     "sea_build_info": (C.c_char_p, []),
     "sea_fastdiv_magic": (_i, [C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "sea_apgd_linf_step": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _i, _i64, _vp]),
+    "sea_apgd_l2_workspace_bytes": (_i64, [_i]),
+    "sea_apgd_l2_step": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _i, _i64, _vp]),
     "sea_linf_random_start": (_i, [_vp, _vp, _f, _vp, _i64, _vp]),
     "sea_linf_project": (_i, [_vp, _vp, _f, _vp, _i64, _vp]),
     "sea_pgd_linf_step": (_i, [_vp, _vp, _vp, _f, _f, _vp, _vp, _i, _i64, _vp]),
@@ -186,6 +188,19 @@ def apgd_linf_step(x, x_adv, x_old, grad, step_b, eps: float, a: float, out=None
     _check(lib().sea_apgd_linf_step(_p(_f32c(x)), _p(_f32c(x_adv)), _p(_f32c(x_old)), _p(_f32c(grad)),
                                     _p(_f32c(step_b)), eps, a, _p(_f32c(out)), B, x[0].numel(), _stream()),
            "sea_apgd_linf_step")
+    return out
+
+
+def apgd_l2_step(x, x_adv, x_old, grad, step_b, eps: float, a: float, out=None, workspace=None):
+    """One APGD L2 update with momentum (reference semseg/attacker.py:412-436): four streaming passes, three deterministic
+    per-image norms.  ``workspace``: sea_apgd_l2_workspace_bytes(B) bytes of device scratch (allocated here when None)."""
+    _dev(x, x_adv, x_old, grad, step_b, out, workspace)
+    B = x.shape[0]
+    out = torch.empty_like(x) if out is None else out
+    if workspace is None:
+        workspace = torch.empty(lib().sea_apgd_l2_workspace_bytes(B) // 8, dtype=torch.float64, device=x.device)
+    _check(lib().sea_apgd_l2_step(_p(_f32c(x)), _p(_f32c(x_adv)), _p(_f32c(x_old)), _p(_f32c(grad)), _p(_f32c(step_b)), eps, a,
+                                  _p(_f32c(out)), _p(workspace), B, x[0].numel(), _stream()), "sea_apgd_l2_step")
     return out
 
 

@@ -458,8 +458,10 @@ class ApgdRun:
     Nothing in ``step`` synchronises with the host."""
 
     def __init__(self, model, x, y, eps, n_iter, loss, track_loss, early_stop, num_classes, weights, x_start,
-                 fuse_upsample=None):
+                 fuse_upsample=None, norm="Linf"):
         self.model = model
+        self.norm = norm               # "Linf" (K1) or "L2" (K1': four streaming passes, reference lines 412-436)
+        self._l2_ws = None
         # fuse the model's final bilinear upsample into the loss kernel when the model offers the hook
         if fuse_upsample is None:
             fuse_upsample = FUSE_UPSAMPLE
@@ -491,7 +493,8 @@ class ApgdRun:
         self.ws_low = None
         self.last = None       # K2 outputs of the latest iterate
         self.k2_events = None  # optional list of (start, end) event pairs, one per step (bench.py)
-        self.use_graph = USE_HIP_GRAPH and n_iter >= GRAPH_MIN_ITER   # capture costs ~3 eager iterations
+        # (capture costs ~3 eager iterations; the L2 step -- on no shipped entry point, SURVEY fact 2 -- keeps the eager loop)
+        self.use_graph = USE_HIP_GRAPH and n_iter >= GRAPH_MIN_ITER and norm == "Linf"
         self.graphs = None
         self._g_xin = self._g_logits = self._ws_pin = None
         self._caller_stream = None
@@ -601,7 +604,13 @@ class ApgdRun:
     def _step_eager(self, i: int):
         # ---- gradient step (reference lines 389-456): K1, then rotate the three iterate buffers
         a = 0.75 if i > 0 else 1.0
-        N.apgd_linf_step(self.x, self.x_adv, self.x_old, self.grad, self.st.step, self.eps, a, out=self.x_next)
+        if self.norm == "L2":
+            if self._l2_ws is None:
+                self._l2_ws = torch.empty(N.lib().sea_apgd_l2_workspace_bytes(self.B) // 8, dtype=torch.float64, device=self.x.device)
+            N.apgd_l2_step(self.x, self.x_adv, self.x_old, self.grad, self.st.step, self.eps, a, out=self.x_next,
+                           workspace=self._l2_ws)
+        else:
+            N.apgd_linf_step(self.x, self.x_adv, self.x_old, self.grad, self.st.step, self.eps, a, out=self.x_next)
         self.x_old, self.x_adv, self.x_next = self.x_adv, self.x_next, self.x_old
         # ---- model forward, fused loss/grad/track/acc/argmax (K2), model input-gradient
         want = i < self.n_iter - 1  # the reference skips the last backward (line 467)
@@ -741,8 +750,15 @@ def apgd_train(model, x, y, norm, eps, n_iter=10, use_rs=False, loss="ce", verbo
     """
     assert not model.training
     assert ignore_index == -1, "Only `ignore_index = 1` is supported."
-    if norm != "Linf":
-        raise NotImplementedError("only the L-inf attack of SEA / PIR-AT is implemented (SURVEY fact 2)")
+    if norm == "L1":
+        raise NotImplementedError("the L1 branch of apgd_train (reference semseg/attacker.py:437-454, 553-566: sparse steps, "
+                                  "L1_projection, adaptive sparsity) is not built: no entry point of the reference reaches it "
+                                  "(SURVEY fact 2; tools/infer.py and tools/train_rob_seg.py pass norm='Linf')")
+    if norm not in ("Linf", "L2"):
+        raise ValueError(f"norm {norm!r}: 'Linf' or 'L2'")
+    if norm == "L2" and use_rs and x_init is None:
+        # reference lines 288-297: the random start exists for L-inf only; there x_adv would be undefined (NameError)
+        raise ValueError("apgd_train(norm='L2', use_rs=True) needs x_init: the reference draws a random start for L-inf only")
     if loss not in N.MODE_BY_NAME:
         raise KeyError(loss)
     if not x.is_cuda:
@@ -751,7 +767,7 @@ def apgd_train(model, x, y, norm, eps, n_iter=10, use_rs=False, loss="ce", verbo
     x = x.detach().contiguous().float()
 
     # ---- start point (reference lines 288-308); the RNG is consumed even when x_init overrides it
-    if not use_rs:
+    if not use_rs or norm != "Linf":
         x_adv = x.clone()
     else:
         t = torch.rand_like(x) if noise is None else noise.to(device)
@@ -760,7 +776,7 @@ def apgd_train(model, x, y, norm, eps, n_iter=10, use_rs=False, loss="ce", verbo
         x_adv = x_init.detach().clone().contiguous().float()
     x_adv = x_adv.clamp_(0.0, 1.0)
 
-    run = ApgdRun(model, x, y, eps, n_iter, loss, track_loss, early_stop, num_classes, weights, x_adv)
+    run = ApgdRun(model, x, y, eps, n_iter, loss, track_loss, early_stop, num_classes, weights, x_adv, norm=norm)
     run.defer = not verbose  # the verbose log line reads the per-image sums on the host
     if logger is not None:
         # reference lines 302-306 log this whenever ignore labels exist (one host read per run, outside the loop)
@@ -862,7 +878,7 @@ def apgd_largereps(model, x, y, weights, norm="Linf", eps=8.0 / 255.0, n_iter=10
     ``return_pred`` also the argmax map of x_adv (so callers such as tools/infer.py need not re-forward it,
     reference tools/infer.py:136-155 + 356-364)."""
     if norm != "Linf":
-        raise NotImplementedError()
+        raise NotImplementedError()     # (the reference's stage re-projection, lines 683-690, raises for every other norm)
     logger = Logger(log_path)
     n_iters, epss = largereps_schedule(n_iter, eps)
     acc = torch.ones([x.shape[0]], device=x.device)

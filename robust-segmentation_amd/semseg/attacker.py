@@ -377,7 +377,7 @@ def _arith_signature(model):
     ``model.training``.  A cached pair whose signature differs is captured again instead of replaying the old arithmetic."""
     import sys
     sig = [bool(getattr(model, "training", False)), torch.is_autocast_enabled(),
-           str(torch.get_autocast_gpu_dtype()) if torch.is_autocast_enabled() else None,
+           str(torch.get_autocast_dtype("cuda")) if torch.is_autocast_enabled() else None,
            N.attn_terms_fwd(), N.attn_terms_bwd(), int(N.lib().sea_gemm_split_pipeline(-1)),
            int(N.lib().sea_gemm_split_mfma_shape(0)), bool(N.AMAX_FROM_PRODUCERS)]
     for name in sorted(sys.modules):

@@ -199,7 +199,7 @@ def test_hip_graph_replay_is_bitwise_the_eager_loop(loss):
     torch.manual_seed(0)
     model = UperNetForSemanticSegmentation("ConvNeXt-T_CVST", 21, None).eval().cuda()
     # 512 x 512: the size at which every kernel of the model path is bitwise reproducible (smaller maps send the PSP
-    # bottleneck to a MIOpen kernel that accumulates with atomics)
+    # bottleneck to a MIOpen kernel that accumulates with atomics, HISTORY §4b)
     x = torch.rand(2, 3, 512, 512, generator=torch.Generator().manual_seed(5)).cuda()
     with torch.no_grad():
         y = model(x).max(1)[1]

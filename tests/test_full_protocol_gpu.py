@@ -7,7 +7,7 @@ are those of a fresh forward of the returned image; the worst-case bookkeeping (
 greedy mIoU <= the mIoU of the attack it starts from); the evaluation is bitwise reproducible (two runs, same summary; at eps 8); the
 captured HIP graph pair and its activation pool are released (device memory back to where it was); and the wall time per step is
 within 15 % of a short measurement of the same step on this box (the sustained rate of the 900-step run: the chip lowers its
-clock under sustained matrix load).
+clock under sustained matrix load, HISTORY §7).
 """
 import gc
 import json

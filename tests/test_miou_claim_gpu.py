@@ -22,7 +22,7 @@ the Mann-Whitney test against them (p = 0.001), and only then were the oneDNN-of
 MIOpen, no kernel of this build) is as far from the CPU reference as the shipped path -- which since round 5 runs under
 pytest (`test_eps8_shipped_is_not_further_from_the_reference_than_stock_pytorch_rocm_fp32`) instead of in a devtool log.
 Every device mode measured so far has a NEGATIVE mean difference against the CPU reference at eps 8 and both CPU re-runs a
-positive one (each |z| < 1.5); the sign and its interval are printed by every run of this file and tracked in DESIGN 5.
+positive one (each |z| < 1.5); the sign and its interval are printed by every run of this file and tracked in HISTORY §5.
 
   eps = 4/255   the claim itself: |diff| <= 0.05 points for aAcc and mIoU, at a sample size whose 95 % interval half-width
                 is itself <= 0.05 (asserted too).
@@ -59,7 +59,7 @@ pytestmark = pytest.mark.gpu
 pytest.importorskip("scipy", reason="the distribution tests (Mann-Whitney, Kolmogorov-Smirnov) need scipy")
 
 # Suite budget: the default `-m gpu` selection runs the eps-8 comparison on TEN committed parts (640 images, 57 s: the
-# set DESIGN 5 quotes); SEA_MIOU_FULL=1 runs every committed part (the builder does, per round, and keeps the log under
+# set HISTORY §5 quotes); SEA_MIOU_FULL=1 runs every committed part (the builder does, per round, and keeps the log under
 # profiles/).  Without the cap this file grows by 5 s per committed part and the suite towards the driver's limit.  Round 5
 # tried a 4-part / 256-image default: on those four parts the device-minus-reference mean sits at z = -2.1 ... -2.75 depending
 # on the box (the attack amplifies last-bit differences, see below), which is a sampling fluctuation the 640-image set does not

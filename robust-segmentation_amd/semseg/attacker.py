@@ -274,14 +274,17 @@ def _input_grad(logits, x_in, dlogits):
     return g if g.is_contiguous() else g.contiguous()
 
 
-# K2u (loss fused with the model's final bilinear upsample; needs `model.forward_lowres`): a MEMORY-SAVING mode, not a fast path.
-# It never materialises the full-resolution logits and their gradient (2.5 GB at B=8, C=151, 512^2) but is 2 x slower than
-# up-sample + K2 + up-sample-backward on every BASELINE config (profiles/r3_cold_kernel_roofline.md), so since round 5 nothing
-# selects it by itself: SEA_FUSE_UPSAMPLE=1 (or fuse_upsample=True) forces it, SEA_FUSE_UPSAMPLE=auto fuses only when the
-# materialised tensors would exceed FUSE_UPSAMPLE_AUTO_BYTES, the default is the unfused path.
-_fu = os.environ.get("SEA_FUSE_UPSAMPLE", "0")
+# K2u (loss fused with the model's final bilinear upsample; needs `model.forward_lowres`).  It never materialises the
+# full-resolution logits and their gradient (2.5 GB at B=8, C=151, 512^2).  Since round 6 the x4 / x16 ratios of the BASELINE
+# models run a kernel with lanes = classes (csrc/loss_upsampled.hip, "power-of-two ratios") that is FASTER than up-sample + K2 +
+# up-sample-backward from two class slots on (C = 151: 629 vs 982 us at x4, 663 vs 906 us at x16, profiles/r6_k2u_bench.log),
+# and slower below (C = 21: 305 vs 140 us -- a third of the lanes idle).  Default "auto": fuse where that kernel applies and
+# C >= FUSE_UPSAMPLE_MIN_CLASSES, or when the materialised tensors would exceed FUSE_UPSAMPLE_AUTO_BYTES (the general gather
+# kernel as a memory-saving mode); SEA_FUSE_UPSAMPLE=1 / 0 (or fuse_upsample=True / False) force / forbid it.
+_fu = os.environ.get("SEA_FUSE_UPSAMPLE", "auto")
 FUSE_UPSAMPLE = "auto" if _fu == "auto" else (_fu == "1")
 FUSE_UPSAMPLE_AUTO_BYTES = 24 * 2 ** 30
+FUSE_UPSAMPLE_MIN_CLASSES = 96
 
 # HIP-graph replay of the middle iterations of an APGD run (see ApgdRun._capture).  SEA_HIP_GRAPH=0 disables it.
 USE_HIP_GRAPH = os.environ.get("SEA_HIP_GRAPH", "1") != "0"
@@ -472,7 +475,11 @@ class ApgdRun:
                 fuse_upsample = False
             elif fuse_upsample == "auto":
                 full = 2 * 4 * x.shape[0] * probe[0].shape[1] * x.shape[-2] * x.shape[-1]  # logits + gradient, fp32
-                fuse_upsample = full > FUSE_UPSAMPLE_AUTO_BYTES
+                lo = probe[0]
+                pow2 = any(x.shape[-2] == r * lo.shape[-2] and x.shape[-1] == r * lo.shape[-1] for r in (4, 16))
+                fast = (pow2 and FUSE_UPSAMPLE_MIN_CLASSES <= lo.shape[1] <= 192 and lo.dtype == torch.float32
+                        and min(lo.shape[-2:]) >= 2 and os.environ.get("SEA_K2U_POW2", "1") != "0")
+                fuse_upsample = fast or full > FUSE_UPSAMPLE_AUTO_BYTES
         else:
             fuse_upsample = False
         self.fused = bool(fuse_upsample)
@@ -501,7 +508,7 @@ class ApgdRun:
         self._first_graph_step = 2   # iterations 0 and 1 of a capturing run are eager (library warm-up on the capture stream)
         # graph mode with a slot: every buffer a captured graph addresses belongs to the slot (and to the next run after this
         # one); the caller's tensors are copied in, the results are copied out (``result``)
-        graph_mode = self.use_graph and not self.fused and n_iter > 3
+        graph_mode = self.use_graph and n_iter > 3
         self.slot = _graph_slot(model, x, num_classes, n_iter) if (graph_mode and x.is_contiguous()) else None
         if self.slot is not None:
             sl = self.slot
@@ -586,7 +593,7 @@ class ApgdRun:
         self.x_next = torch.empty_like(self.x_adv)
 
     def step(self, i: int):
-        if self.use_graph and not self.fused and self.n_iter > 3:
+        if self.use_graph and self.n_iter > 3:
             if self._first_graph_step <= i < self.n_iter - 1:
                 return self._step_graph(i)
             if i == 1:
@@ -706,7 +713,7 @@ class ApgdRun:
     def _graph_sig(self):
         """what a captured pair bakes in besides addresses and weights: K7's early-stop flag, where it finds K2's sums, and
         the process-global arithmetic state of the model's forward / backward (``_arith_signature``)"""
-        return (bool(self.early_stop), bool(self.defer), _arith_signature(self.model))
+        return (bool(self.early_stop), bool(self.defer), bool(self.fused), _arith_signature(self.model))
 
     def _step_graph(self, i: int):
         if self.graphs is not None and self.slot is not None and i == self._first_graph_step:

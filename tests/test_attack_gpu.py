@@ -221,6 +221,46 @@ def test_hip_graph_replay_is_bitwise_the_eager_loop(loss):
     assert (outs[0][3] - x).abs().max() <= 8.0 / 255 + 1e-6
 
 
+def test_hip_graph_replay_with_the_fused_upsample_loss_is_bitwise_the_eager_loop():
+    """Round 6: K2u (loss fused with the model's final x4 up-sampling, lanes = classes) is the default from 96 classes on, so
+    the graph mode has to carry it: graph A captures `forward_lowres`, the eager launch between the graphs is K2u, graph B
+    back-propagates from the low-resolution gradient.  UperNet-ConvNeXt-T with 151 classes at 256 x 256, graph replay
+    against the eager loop bit for bit, and both against the unfused path to the tolerance of two correct arithmetics."""
+    from semseg import attacker as A
+    from semseg.models import UperNetForSemanticSegmentation
+    from semseg.utils.utils import ADE_WTS
+    torch.manual_seed(0)
+    model = UperNetForSemanticSegmentation("ConvNeXt-T_CVST", 151, None).eval().cuda()
+    x = torch.rand(2, 3, 512, 512, generator=torch.Generator().manual_seed(5)).cuda()
+    with torch.no_grad():
+        y = model(x).max(1)[1]
+    y[0, :4] = -1
+    w = torch.tensor(ADE_WTS).cuda()[:151]
+    noise = torch.rand(x.shape, generator=torch.Generator().manual_seed(6)).cuda()
+    runs = {}
+    seen = []
+    real = A.N.loss_fwd_bwd_upsampled
+    A.N.loss_fwd_bwd_upsampled = lambda *a, **k: (seen.append(1), real(*a, **k))[1]
+    old = (A.USE_HIP_GRAPH, A.FUSE_UPSAMPLE)
+    try:
+        for tag, graph, fuse in (("eager", False, "auto"), ("graph", True, "auto"), ("unfused", True, False)):
+            A.USE_HIP_GRAPH, A.FUSE_UPSAMPLE = graph, fuse
+            A.release_graph_cache(model)
+            n0 = len(seen)
+            runs[tag] = A.apgd_train(model, x, y, "Linf", 8.0 / 255, n_iter=20, use_rs=True, loss="mask-ce-bal", early_stop=True,
+                                     track_loss="ce-avg", num_classes=151, weights=w, noise=noise, return_pred=True)
+            assert (len(seen) > n0) == (fuse == "auto"), "the default did not pick K2u at 151 classes" if fuse == "auto" else "K2u ran although forbidden"
+    finally:
+        A.USE_HIP_GRAPH, A.FUSE_UPSAMPLE = old
+        A.N.loss_fwd_bwd_upsampled = real
+        A.release_graph_cache(model)
+    for a, b in zip(runs["eager"], runs["graph"]):
+        assert torch.equal(a, b)
+    # fused vs unfused: the same attack up to rounding (the interpolated logits are bit-identical, the loss sums are not)
+    assert (runs["graph"][1] - runs["unfused"][1]).abs().max().item() <= 0.02
+    torch.testing.assert_close(runs["graph"][2], runs["unfused"][2], rtol=2e-2, atol=1e-3)
+
+
 @pytest.mark.parametrize("where", ["forward", "backward"])
 def test_hip_graph_capture_failure_falls_back_to_the_eager_loop(where, capfd):
     """A model that cannot be captured (a host synchronisation inside its forward, or inside its backward) must keep

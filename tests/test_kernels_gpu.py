@@ -325,6 +325,10 @@ def test_convnext_block_uses_stencil_kernel_and_matches_miopen(N):
     (2, 151, 12, 20, 48, 80),     # many classes, non-square
     (1, 3, 7, 5, 7, 5),           # scale 1
     (3, 21, 13, 11, 50, 45),      # ragged tiles + non-integer scales
+    (2, 151, 8, 12, 32, 48),      # x4, three class slots of the power-of-two kernel (lanes = classes), non-square
+    (1, 65, 6, 7, 24, 28),        # x4, two slots, one class in the second
+    (2, 128, 3, 5, 48, 80),       # x16, two full slots, segments of two cells with a ragged last one
+    (1, 192, 2, 2, 8, 8),         # x4, the smallest map the power-of-two kernel takes, 192 classes
 ])
 @pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_fused_upsample_loss_kernel(N, case, mode):

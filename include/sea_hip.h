@@ -505,9 +505,23 @@ int sea_gemm_split(const float* A, int64_t lda, const void* Wp, float* C, int64_
  *     bounds of sea_gemm_split_f16's comment); amax_mul_dev: ONE float, rowmax|g[r]| * it bounds row r of (g W2) GELU'
  *     (SeaGemmEpilogue.a_amax_mul_dev).  b2 / res may be NULL. */
 int sea_mlp_fused_supported(int C, int H);
+/* The same pair with the block's LayerNorm (over the C channels, affine ln_w / ln_b, eps) in front of the MLP
+ * (convnext_orig.py:75-77: norm -> pwconv1): x is the LayerNorm's INPUT, amax_x bounds its OUTPUT; the backward returns the
+ * gradient w.r.t. x (frozen affine parameters).  The channel sums follow sea_layernorm_fwd / _bwd's summation order: replaces
+ * those two launches and the round trip of the normalised tensor without changing a bit. */
+int sea_ln_mlp_fused_fwd(const float* x, int64_t ldx, const float* ln_w, const float* ln_b, float ln_eps, const void* W1p,
+                         const float* b1, const void* W2p, const float* b2, const float* res, int64_t ldres, float* y,
+                         int64_t ldy, int M, int C, int H, const uint32_t* amax_x, const uint32_t* amax_h, void* stream);
+int sea_ln_mlp_fused_bwd(const float* g, int64_t ldg, const float* x, int64_t ldx, const float* ln_w, const float* ln_b,
+                         float ln_eps, const void* W1p, const float* b1, const void* W2tp, const void* W1tp, float* dx,
+                         int64_t lddx, int M, int C, int H, const uint32_t* amax_x, const float* amax_mul_dev, void* stream);
 /* test probe: out[0], out[1] (two pre-zeroed 64-bit device words) += the number of fp32 bit patterns for which the branch-free
  * GELU / GELU' evaluation inside the fused kernels differs from the one of sea_gemm_split's prologues (must stay 0, 0) */
 int sea_probe_gelu_mismatches(unsigned long long* out, void* stream);
+/* test probe: the LayerNorm of the fused kernels' prologue on its own (x dense (M, C), C in {96, 192}): yn, mean, rstd must equal
+ * sea_layernorm_fwd's bit for bit */
+int sea_probe_ln_rows(const float* x, const float* ln_w, const float* ln_b, float eps, int M, int C, float* yn, float* mean,
+                      float* rstd, void* stream);
 /* diagnostic build of the C = 96 fused kernels with s_memtime stamps around the segments of a loop iteration
  * (devtools/mlp_fused_stamps.py); dbg: 8 uint64 per wave.  W2p: pack(w2) forward, pack(w2, trans) backward. */
 int sea_mlp_fused_stamps(int bwd, const float* g, int64_t ldg, const float* x, int64_t ldx, const void* W1p, const float* b1,

@@ -48,6 +48,9 @@ struct MlpArgs {
   const uint32_t* amax1; // float bits of a bound of max|x| (one word: the LayerNorm bound)
   const uint32_t* amax2; // forward: float bits of a bound of max|GELU(t)| (one word)
   unsigned long long* dbg; // diagnostic builds only (STAMP): per wave 8 words of accumulated s_memtime ticks
+  const float* ln_w;     // optional: x is the INPUT of a LayerNorm over its C channels (affine ln_w, ln_b, eps ln_eps) whose output
+  const float* ln_b;     // feeds the MLP: normalised in the prologue (forward and backward), differentiated in the backward's epilogue
+  float ln_eps;
   const float* amax_mul; // backward: ONE float, rowmax(g[r]) * this bounds |(g W2)[r][:] GELU'| (SeaGemmEpilogue.a_amax_mul_dev)
 };
 
@@ -116,6 +119,80 @@ __device__ __forceinline__ void static_for_impl(Fn&& f, std::integer_sequence<in
 template <int N, class Fn>
 __device__ __forceinline__ void static_for(Fn&& f) {
   static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+
+// probe: the LayerNorm of the fused kernels' prologue on its own (tests: against sea_layernorm_fwd bit for bit)
+template <int C>
+__global__ __launch_bounds__(256) void ln_rows_probe_kernel(const float* x, const float* ln_w, const float* ln_b, float eps, int M,
+                                                            float* yn, float* mean, float* rstd) {
+  constexpr int KS = C / 16;
+  constexpr int LN_KSP = C <= 128 ? 8 : 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  int row = (blockIdx.x * 4 + wave) * 32 + r;
+  const bool live = row < M;
+  row = live ? row : M - 1;
+  f32x4 xa[KS][2];
+  const float* const xr = x + (int64_t)row * C + 8 * h;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    xa[ks][0] = *(const f32x4*)(xr + 16 * ks);
+    xa[ks][1] = *(const f32x4*)(xr + 16 * ks + 4);
+  }
+  const float ln_inv_c = 1.f / (float)C;
+  auto ln_tree = [&](float (&t)[2][LN_KSP]) __attribute__((always_inline)) -> float {
+#pragma unroll
+    for (int o = LN_KSP / 2; o > 0; o >>= 1)
+#pragma unroll
+      for (int i = 0; i < o; ++i) {
+        t[0][i] += t[0][i + o];
+        t[1][i] += t[1][i + o];
+      }
+    const float a0 = t[0][0] + __shfl_xor(t[0][0], 32, 64), a1 = t[1][0] + __shfl_xor(t[1][0], 32, 64);
+    return a0 + a1;
+  };
+  float t[2][LN_KSP];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < LN_KSP; ++i) t[j][i] = i < KS ? (xa[i < KS ? i : 0][j][0] + xa[i < KS ? i : 0][j][1]) + (xa[i < KS ? i : 0][j][2] + xa[i < KS ? i : 0][j][3]) : 0.f;
+  float mu;
+  {
+#pragma clang fp contract(off)
+    mu = ln_tree(t) * ln_inv_c;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < LN_KSP; ++i) {
+        if (i < KS) {
+          const float dx = xa[i][j][0] - mu, dy = xa[i][j][1] - mu, dz = xa[i][j][2] - mu, dw = xa[i][j][3] - mu;
+          t[j][i] = fmaf(dx, dx, dy * dy) + fmaf(dz, dz, dw * dw);
+        } else {
+          t[j][i] = 0.f;
+        }
+      }
+  }
+  const float rs = rsqrtf(fmaf(ln_tree(t), ln_inv_c, eps));
+  if (live) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const f32x4 wv = *(const f32x4*)(ln_w + 16 * ks + 8 * h + 4 * j), bv = *(const f32x4*)(ln_b + 16 * ks + 8 * h + 4 * j);
+        f32x4 o;
+        {
+#pragma clang fp contract(off)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = fmaf((xa[ks][j][e] - mu) * rs, wv[e], bv[e]);
+        }
+        *(f32x4*)(yn + (int64_t)row * C + 16 * ks + 8 * h + 4 * j) = o;
+      }
+    if (h == 0) {
+      mean[row] = mu;
+      rstd[row] = rs;
+    }
+  }
 }
 
 __device__ __forceinline__ f32x16 mfma3(const u32x4 w_hi, const u32x4 w_mid, const u32x4 a_hi, const u32x4 a_mid, f32x16 c) {
@@ -230,9 +307,65 @@ __global__ __launch_bounds__(WAVES * 64, (C <= 96 ? 8 : 4) / 4) void mlp_fused_k
   float sc1, inv1;
   pow2_scale(*p.amax1, sc1, inv1);
   u32x4 xf[KS][2];
+  // LayerNorm in front of the MLP (ConvNeXt: norm -> pwconv1, convnext_orig.py:75-77), optional.  The sums over the channels
+  // are taken in the order of ln_fwd_kernel / ln_bwd_kernel (csrc/ln_kernels.hip: one float4 per lane of a 32- or 64-lane
+  // group, (a + b) + (c + d) per float4, then an xor-shuffle tree from the highest index bit down), so that fusing the
+  // LayerNorm in changes no bit: here float4 v = 4 ks + 2 h + j sits in lane half h, and the tree's levels are the bits of
+  // ks (in the lane), then h (one exchange between the two halves), then j (in the lane).
+  constexpr int LN_KSP = C <= 128 ? 8 : 16;      // float4 slots per (h, j) of the kernel's lane group (32 lanes: 8, 64 lanes: 16)
+  const float ln_inv_c = 1.f / (float)C;
+  auto ln_tree = [&](float (&t)[2][LN_KSP]) __attribute__((always_inline)) -> float {
+#pragma unroll
+    for (int o = LN_KSP / 2; o > 0; o >>= 1)
+#pragma unroll
+      for (int i = 0; i < o; ++i) {
+        t[0][i] += t[0][i + o];
+        t[1][i] += t[1][i + o];
+      }
+    const float a0 = t[0][0] + __shfl_xor(t[0][0], 32, 64), a1 = t[1][0] + __shfl_xor(t[1][0], 32, 64);
+    return a0 + a1;
+  };
+  float ln_mu = 0.f, ln_rs = 1.f;
   {
     f32x4 xa[KS][2];
     load_rows(p.x, p.ldx, xa);
+    if (p.ln_w != nullptr) {
+      float t[2][LN_KSP];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < LN_KSP; ++i) t[j][i] = i < KS ? (xa[i < KS ? i : 0][j][0] + xa[i < KS ? i : 0][j][1]) + (xa[i < KS ? i : 0][j][2] + xa[i < KS ? i : 0][j][3]) : 0.f;
+      // (contraction off, fused operations written out: the LayerNorm kernel's COMPILED arithmetic -- fma(dx, dx, dy dy) +
+      // fma(dz, dz, dw dw) per float4, fma(sum, 1 / C, eps) -- not whatever fusion this context would invite: without the
+      // pragma hipcc turns x - sum * (1 / C) into one v_fmamk here)
+      {
+#pragma clang fp contract(off)
+        ln_mu = ln_tree(t) * ln_inv_c;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < LN_KSP; ++i) {
+            if (i < KS) {
+              const float dx = xa[i][j][0] - ln_mu, dy = xa[i][j][1] - ln_mu, dz = xa[i][j][2] - ln_mu, dw = xa[i][j][3] - ln_mu;
+              t[j][i] = fmaf(dx, dx, dy * dy) + fmaf(dz, dz, dw * dw);
+            } else {
+              t[j][i] = 0.f;
+            }
+          }
+      }
+      ln_rs = rsqrtf(fmaf(ln_tree(t), ln_inv_c, p.ln_eps));
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const f32x4 wv = *(const f32x4*)(p.ln_w + 16 * ks + 8 * h + 4 * j), bv = *(const f32x4*)(p.ln_b + 16 * ks + 8 * h + 4 * j);
+          {
+#pragma clang fp contract(off)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xa[ks][j][e] = fmaf((xa[ks][j][e] - ln_mu) * ln_rs, wv[e], bv[e]);
+          }
+        }
+    }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) split8(xa[ks][0], xa[ks][1], sc1, xf[ks][0], xf[ks][1]);
   }
@@ -531,8 +664,73 @@ __global__ __launch_bounds__(WAVES * 64, (C <= 96 ? 8 : 4) / 4) void mlp_fused_k
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[n][4 * q + e] * (inv2 * wb[e]) + bb[e];
+        if constexpr (BWD) {
+          if (p.ln_w != nullptr) {       // keep the row's gradient w.r.t. the LayerNorm OUTPUT in the accumulators: differentiated below
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[n][4 * q + e] = v[e];
+            continue;
+          }
+        }
         *(f32x4*)(ep + r * LDP + col * 4) = v;
       }
+    if constexpr (BWD) {
+      if (p.ln_w != nullptr) {
+        // ---- input gradient of the LayerNorm (ln_bwd_kernel's arithmetic and summation order): float4 v = 8 n + 2 q + h of the
+        // row sits in accumulator quad (n, q) of lane half h; tree levels: the bits of n, then of q (in the lane), then h
+        constexpr int NTP = C <= 128 ? 4 : 8;
+        const float* const xr = p.x + (int64_t)row * p.ldx;
+        float t1[NTP][4], t2[NTP][4];
+        f32x4 gw[NT][4], xh[NT][4];
+#pragma unroll
+        for (int n = 0; n < NTP; ++n)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (n < NT) {
+              const int col = 32 * n + 8 * q + 4 * h;
+              const f32x4 wv = *(const f32x4*)(p.ln_w + col), xv = *(const f32x4*)(xr + col);
+              const int nn = n < NT ? n : 0;
+              {
+#pragma clang fp contract(off)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  gw[nn][q][e] = acc[nn][4 * q + e] * wv[e];
+                  xh[nn][q][e] = (xv[e] - ln_mu) * ln_rs;
+                }
+                t1[n][q] = (gw[nn][q][0] + gw[nn][q][1]) + (gw[nn][q][2] + gw[nn][q][3]);
+                t2[n][q] = (gw[nn][q][0] * xh[nn][q][0] + gw[nn][q][1] * xh[nn][q][1]) + (gw[nn][q][2] * xh[nn][q][2] + gw[nn][q][3] * xh[nn][q][3]);
+              }
+            } else {
+              t1[n][q] = 0.f;
+              t2[n][q] = 0.f;
+            }
+          }
+#pragma unroll
+        for (int o = NTP / 2; o > 0; o >>= 1)
+#pragma unroll
+          for (int i = 0; i < o; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              t1[i][q] += t1[i + o][q];
+              t2[i][q] += t2[i + o][q];
+            }
+        float s1 = (t1[0][0] + t1[0][2]) + (t1[0][1] + t1[0][3]), s2 = (t2[0][0] + t2[0][2]) + (t2[0][1] + t2[0][3]);
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 o4;
+            {
+#pragma clang fp contract(off)
+              const float m1 = s1 * ln_inv_c, m2 = s2 * ln_inv_c;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o4[e] = ln_rs * fmaf(-xh[n][q][e], m2, gw[n][q][e] - m1);
+            }
+            *(f32x4*)(ep + r * LDP + (32 * n + 8 * q + 4 * h) * 4) = o4;
+          }
+      }
+    }
     const bool has_res = !BWD && p.res != nullptr;
 #pragma unroll
     for (int it = 0; it < NF4; ++it) {
@@ -593,6 +791,17 @@ static const int g_mlp_eps = [] {   // (A/B knob: elements per micro-step of the
   return (e && e[0] == '2') ? 2 : 4;
 }();
 
+extern "C" int sea_probe_ln_rows(const float* x, const float* ln_w, const float* ln_b, float eps, int M, int C, float* yn, float* mean,
+                                 float* rstd, void* stream) {
+  SEA_CHECK_ARG(x && ln_w && ln_b && yn && mean && rstd && M > 0 && (C == 96 || C == 192));
+  const dim3 grid((M + 127) / 128), block(256);
+  if (C == 96)
+    hipLaunchKernelGGL(ln_rows_probe_kernel<96>, grid, block, 0, (hipStream_t)stream, x, ln_w, ln_b, eps, M, yn, mean, rstd);
+  else
+    hipLaunchKernelGGL(ln_rows_probe_kernel<192>, grid, block, 0, (hipStream_t)stream, x, ln_w, ln_b, eps, M, yn, mean, rstd);
+  SEA_RETURN_LAST();
+}
+
 extern "C" int sea_mlp_fused_supported(int C, int H) { return (H == 4 * C && (C == 96 || C == 192)) ? 1 : 0; }
 
 static bool mlp_common_ok(const MlpArgs& p, int C) {
@@ -601,10 +810,12 @@ static bool mlp_common_ok(const MlpArgs& p, int C) {
          ((((uintptr_t)p.x) | ((uintptr_t)p.y) | ((uintptr_t)p.Wa) | ((uintptr_t)p.Wb) | ((uintptr_t)p.b1)) & 15) == 0;
 }
 
-extern "C" int sea_mlp_fused_fwd(const float* x, int64_t ldx, const void* W1p, const float* b1, const void* W2p, const float* b2,
-                                 const float* res, int64_t ldres, float* y, int64_t ldy, int M, int C, int H,
-                                 const uint32_t* amax_x, const uint32_t* amax_h, void* stream) {
+static int mlp_fwd_impl(const float* x, int64_t ldx, const void* W1p, const float* b1, const void* W2p, const float* b2,
+                        const float* res, int64_t ldres, float* y, int64_t ldy, int M, int C, int H, const uint32_t* amax_x,
+                        const uint32_t* amax_h, const float* ln_w, const float* ln_b, float ln_eps, void* stream) {
   MlpArgs p = {};
+  p.ln_w = ln_w; p.ln_b = ln_b; p.ln_eps = ln_eps;
+  SEA_CHECK_ARG((ln_w == nullptr) == (ln_b == nullptr) && ((((uintptr_t)ln_w) | ((uintptr_t)ln_b)) & 15) == 0);
   p.x = x; p.ldx = ldx; p.Wa = (const char*)W1p; p.Wb = (const char*)W2p; p.b1 = b1; p.b2 = b2; p.res = res; p.ldres = ldres;
   p.y = y; p.ldy = ldy; p.M = M; p.H = H; p.Npad = (C + GS_BN - 1) / GS_BN * GS_BN; p.amax1 = amax_x; p.amax2 = amax_h;
   SEA_CHECK_ARG(mlp_common_ok(p, C) && amax_h != nullptr);
@@ -615,10 +826,25 @@ extern "C" int sea_mlp_fused_fwd(const float* x, int64_t ldx, const void* W1p, c
   return mlp_launch<192, 4, false, true>(p, st);
 }
 
-extern "C" int sea_mlp_fused_bwd(const float* g, int64_t ldg, const float* x, int64_t ldx, const void* W1p, const float* b1,
-                                 const void* W2tp, const void* W1tp, float* dx, int64_t lddx, int M, int C, int H,
-                                 const uint32_t* amax_x, const float* amax_mul_dev, void* stream) {
+extern "C" int sea_mlp_fused_fwd(const float* x, int64_t ldx, const void* W1p, const float* b1, const void* W2p, const float* b2,
+                                 const float* res, int64_t ldres, float* y, int64_t ldy, int M, int C, int H,
+                                 const uint32_t* amax_x, const uint32_t* amax_h, void* stream) {
+  return mlp_fwd_impl(x, ldx, W1p, b1, W2p, b2, res, ldres, y, ldy, M, C, H, amax_x, amax_h, nullptr, nullptr, 0.f, stream);
+}
+// the same with a LayerNorm over the C channels of x in front (x = its INPUT; amax_x bounds its OUTPUT): convnext_orig.py:75-79
+extern "C" int sea_ln_mlp_fused_fwd(const float* x, int64_t ldx, const float* ln_w, const float* ln_b, float ln_eps, const void* W1p,
+                                    const float* b1, const void* W2p, const float* b2, const float* res, int64_t ldres, float* y,
+                                    int64_t ldy, int M, int C, int H, const uint32_t* amax_x, const uint32_t* amax_h, void* stream) {
+  SEA_CHECK_ARG(ln_w && ln_b);
+  return mlp_fwd_impl(x, ldx, W1p, b1, W2p, b2, res, ldres, y, ldy, M, C, H, amax_x, amax_h, ln_w, ln_b, ln_eps, stream);
+}
+
+static int mlp_bwd_impl(const float* g, int64_t ldg, const float* x, int64_t ldx, const void* W1p, const float* b1,
+                        const void* W2tp, const void* W1tp, float* dx, int64_t lddx, int M, int C, int H, const uint32_t* amax_x,
+                        const float* amax_mul_dev, const float* ln_w, const float* ln_b, float ln_eps, void* stream) {
   MlpArgs p = {};
+  p.ln_w = ln_w; p.ln_b = ln_b; p.ln_eps = ln_eps;
+  SEA_CHECK_ARG((ln_w == nullptr) == (ln_b == nullptr) && ((((uintptr_t)ln_w) | ((uintptr_t)ln_b)) & 15) == 0);
   p.x = x; p.ldx = ldx; p.g = g; p.ldg = ldg; p.Wa = (const char*)W1p; p.Wu = (const char*)W2tp; p.Wb = (const char*)W1tp;
   p.b1 = b1; p.y = dx; p.ldy = lddx; p.M = M; p.H = H; p.Npad = (C + GS_BN - 1) / GS_BN * GS_BN; p.amax1 = amax_x;
   p.amax_mul = amax_mul_dev;
@@ -628,6 +854,20 @@ extern "C" int sea_mlp_fused_bwd(const float* g, int64_t ldg, const float* x, in
   if (g_mlp_eps == 2) return C == 96 ? mlp_launch<96, 4, true, false, false, 2>(p, st) : mlp_launch<192, 4, true, true, false, 2>(p, st);
   if (C == 96) return mlp_launch<96, 4, true, false>(p, st);
   return mlp_launch<192, 4, true, true>(p, st);
+}
+
+extern "C" int sea_mlp_fused_bwd(const float* g, int64_t ldg, const float* x, int64_t ldx, const void* W1p, const float* b1,
+                                 const void* W2tp, const void* W1tp, float* dx, int64_t lddx, int M, int C, int H,
+                                 const uint32_t* amax_x, const float* amax_mul_dev, void* stream) {
+  return mlp_bwd_impl(g, ldg, x, ldx, W1p, b1, W2tp, W1tp, dx, lddx, M, C, H, amax_x, amax_mul_dev, nullptr, nullptr, 0.f, stream);
+}
+// input gradient of sea_ln_mlp_fused_fwd w.r.t. the LayerNorm's INPUT x (frozen affine parameters)
+extern "C" int sea_ln_mlp_fused_bwd(const float* g, int64_t ldg, const float* x, int64_t ldx, const float* ln_w, const float* ln_b,
+                                    float ln_eps, const void* W1p, const float* b1, const void* W2tp, const void* W1tp, float* dx,
+                                    int64_t lddx, int M, int C, int H, const uint32_t* amax_x, const float* amax_mul_dev,
+                                    void* stream) {
+  SEA_CHECK_ARG(ln_w && ln_b);
+  return mlp_bwd_impl(g, ldg, x, ldx, W1p, b1, W2tp, W1tp, dx, lddx, M, C, H, amax_x, amax_mul_dev, ln_w, ln_b, ln_eps, stream);
 }
 
 // Diagnostic build of the C = 96 kernels (devtools/mlp_fused_stamps.py): the same kernel with s_memtime stamps around the

@@ -99,9 +99,12 @@ _SIGS = {
     "sea_gemm_split": (_i, [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _vp]),
     "sea_mlp_fused_supported": (_i, [_i, _i]),
     "sea_probe_gelu_mismatches": (_i, [_vp, _vp]),
+    "sea_probe_ln_rows": (_i, [_vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp]),
     "sea_mlp_fused_stamps": (_i, [_i, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "sea_mlp_fused_fwd": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp, _vp, _vp]),
     "sea_mlp_fused_bwd": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp]),
+    "sea_ln_mlp_fused_fwd": (_i, [_vp, _i64, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp, _vp, _vp]),
+    "sea_ln_mlp_fused_bwd": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp]),
     "sea_gemm_split_mfma_shape": (_i, [_i]),
     "sea_gemm_split_pipeline": (_i, [_i]),
     "sea_probe_stream_copy": (_i, [_vp, _vp, _sz, _i, _vp]),
@@ -965,11 +968,23 @@ def _mlp_rows(t, C, what):
         raise SeaNativeError(f"mlp_fused: {what} must be float32 (M, {C}) rows, 16-byte aligned, row stride % 4 == 0")
 
 
-def mlp_fused_forward(x2, W1p: PackedWeight, b1, W2p: PackedWeight, b2, res, amax_x, amax_h, out=None):
+def _ln_args(ln, Cc):
+    if ln is None:
+        return None
+    w, b, eps = ln
+    if (w.dtype != torch.float32 or b.dtype != torch.float32 or w.numel() != Cc or b.numel() != Cc or not w.is_contiguous()
+            or not b.is_contiguous() or w.data_ptr() % 16 or b.data_ptr() % 16):
+        raise SeaNativeError("mlp_fused: LayerNorm weight / bias must be contiguous, 16-byte aligned float32 of C entries")
+    return w, b, float(eps)
+
+
+def mlp_fused_forward(x2, W1p: PackedWeight, b1, W2p: PackedWeight, b2, res, amax_x, amax_h, out=None, ln=None):
     """out = res + W2 GELU(W1 x2 + b1) + b2 in ONE kernel (sea_mlp_fused_fwd): the hidden tensor never leaves the CU.  W1p / W2p:
     the fp16 x 2 packs (terms 22) of w1 (H x C) and w2 (C x H); amax_x / amax_h: one int32 device word each, float bits of a
-    bound of max|x2| and of max|GELU(W1 x2 + b1)|.  Bit for bit the two gemm_split launches (a_gelu prologue) plus the add."""
-    _dev(x2, b1, b2, res, out, amax_x, amax_h)
+    bound of max|x2| and of max|GELU(W1 x2 + b1)|.  Bit for bit the two gemm_split launches (a_gelu prologue) plus the add.
+    ``ln`` = (weight, bias, eps): x2 is the INPUT of a LayerNorm over its channels whose output feeds the MLP (amax_x then bounds
+    that output); the normalisation runs in the kernel's prologue with ``layernorm``'s arithmetic and summation order."""
+    _dev(x2, b1, b2, res, out, amax_x, amax_h, *(ln[:2] if ln is not None else ()))
     M, Cc = x2.shape
     H = W1p.N
     if (W1p.terms, W2p.terms, W1p.K, W2p.N, W2p.K, W1p.batch, W2p.batch) != (22, 22, Cc, Cc, H, 1, 1):
@@ -980,13 +995,20 @@ def mlp_fused_forward(x2, W1p: PackedWeight, b1, W2p: PackedWeight, b2, res, ama
     if out is None:
         out = torch.empty(M, Cc, dtype=torch.float32, device=x2.device)
     _mlp_rows(out, Cc, "out")
+    la = _ln_args(ln, Cc)
+    if la is not None:
+        _check(lib().sea_ln_mlp_fused_fwd(_p(x2), x2.stride(0), _p(la[0]), _p(la[1]), la[2], _p(W1p.data), _p(b1), _p(W2p.data),
+                                          _p(b2), _p(res), res.stride(0) if res is not None else 0, _p(out), out.stride(0), M, Cc,
+                                          H, _p(amax_x), _p(amax_h), _stream()), "sea_ln_mlp_fused_fwd")
+        return out
     _check(lib().sea_mlp_fused_fwd(_p(x2), x2.stride(0), _p(W1p.data), _p(b1), _p(W2p.data), _p(b2), _p(res),
                                    res.stride(0) if res is not None else 0, _p(out), out.stride(0), M, Cc, H, _p(amax_x),
                                    _p(amax_h), _stream()), "sea_mlp_fused_fwd")
     return out
 
 
-def mlp_fused_backward(g2, x2, W1p: PackedWeight, b1, W2tp: PackedWeight, W1tp: PackedWeight, amax_x, amax_mul, out=None):
+def mlp_fused_backward(g2, x2, W1p: PackedWeight, b1, W2tp: PackedWeight, W1tp: PackedWeight, amax_x, amax_mul, out=None,
+                       ln=None):
     """input gradient of ``mlp_fused_forward`` w.r.t. x2 (sea_mlp_fused_bwd): t = W1 x2 + b1 is recomputed, u = g2 W2 and
     dx = (u GELU'(t)) W1 follow in the same kernel.  W2tp / W1tp: the packs of w2 and w1 with trans=True (the operands of the
     two input-gradient products); amax_mul: ONE float32 on the device, rowmax|g2[r]| * amax_mul bounds row r of u GELU'(t).
@@ -1002,6 +1024,13 @@ def mlp_fused_backward(g2, x2, W1p: PackedWeight, b1, W2tp: PackedWeight, W1tp: 
     if out is None:
         out = torch.empty(M, Cc, dtype=torch.float32, device=x2.device)
     _mlp_rows(out, Cc, "out")
+    la = _ln_args(ln, Cc)
+    if la is not None:       # x2 is the LayerNorm's input; the result is the gradient w.r.t. THAT (frozen affine parameters)
+        _dev(*la[:2])
+        _check(lib().sea_ln_mlp_fused_bwd(_p(g2), g2.stride(0), _p(x2), x2.stride(0), _p(la[0]), _p(la[1]), la[2], _p(W1p.data),
+                                          _p(b1), _p(W2tp.data), _p(W1tp.data), _p(out), out.stride(0), M, Cc, H, _p(amax_x),
+                                          _p(amax_mul), _stream()), "sea_ln_mlp_fused_bwd")
+        return out
     _check(lib().sea_mlp_fused_bwd(_p(g2), g2.stride(0), _p(x2), x2.stride(0), _p(W1p.data), _p(b1), _p(W2tp.data),
                                    _p(W1tp.data), _p(out), out.stride(0), M, Cc, H, _p(amax_x), _p(amax_mul), _stream()),
            "sea_mlp_fused_bwd")

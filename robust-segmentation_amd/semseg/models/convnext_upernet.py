@@ -460,10 +460,11 @@ class _FrozenMlp(torch.autograd.Function):
 
     @staticmethod
     @_fp32_fwd
-    def forward(ctx, x, w1, b1, w2, b2, res, caches, a1, a2):
+    def forward(ctx, x, w1, b1, w2, b2, res, caches, a1, a2, ln=None):
         from .. import _native as N
         terms = _terms()
         x2 = x.reshape(-1, x.shape[-1])
+        ctx.ln = None
         if terms != 22:
             a1 = a2 = None
         fuse, nb = int(FUSE_MLP), (x.shape[0] if x.dim() > 2 else 1)
@@ -477,11 +478,15 @@ class _FrozenMlp(torch.autograd.Function):
         if (terms == 22 and fuse & 16 and a1 is not None and a2 is not None and a1.numel() == 1 and a2.numel() == 1
                 and b1 is not None and N.mlp_fused_ok(w2.shape[0], w1.shape[0]) and rows_ok(x2)
                 and (r2 is None or rows_ok(r2))):
+            # ``ln`` = (weight, bias, eps) of the block's LayerNorm: x is then its INPUT and the normalisation (and, backward, its
+            # input gradient) runs inside the kernels too, with the LayerNorm kernel's own arithmetic (see _mlp_takes_layernorm)
             y = N.mlp_fused_forward(x2, _packed(w1, caches[0], "lin_fwd", False, terms), b1,
-                                    _packed(w2, caches[1], "lin_fwd", False, terms), b2, r2, a1, a2)
-            ctx.kernel_fused = True
+                                    _packed(w2, caches[1], "lin_fwd", False, terms), b2, r2, a1, a2, ln=ln)
+            ctx.kernel_fused, ctx.ln = True, ln
             ctx.save_for_backward(x2)
             return y.view(x.shape)
+        if ln is not None:
+            raise RuntimeError("_FrozenMlp: a LayerNorm was handed in but the fused kernel does not apply (see _mlp_takes_layernorm)")
         ctx.kernel_fused = False
         t = torch.empty(x2.shape[0], w1.shape[0], dtype=torch.float32, device=x.device)
         pro = bool(fuse & 16) and -(-w2.shape[0] // 128) <= FUSE_PROLOGUE_MAX_NBLOCKS and not fuse & 1
@@ -521,8 +526,11 @@ class _FrozenMlp(torch.autograd.Function):
             if terms == 22 and g2.data_ptr() % 16 == 0:
                 gx = N.mlp_fused_backward(g2, x2, p1f, ctx.b1, _packed(ctx.w[1], ctx.caches[1], "lin_bwd", True, terms),
                                           _packed(ctx.w[0], ctx.caches[0], "lin_bwd", True, terms), ctx.a1,
-                                          _l1_bound(ctx.w[1], ctx.caches[1], dim=0, factor=1.13))
-                return gx.view(ctx.shape), None, None, None, None, (g if ctx.has_res else None), None, None, None
+                                          _l1_bound(ctx.w[1], ctx.caches[1], dim=0, factor=1.13), ln=ctx.ln)
+                return gx.view(ctx.shape), None, None, None, None, (g if ctx.has_res else None), None, None, None, None
+            if ctx.ln is not None:                                               # (the LayerNorm lived in the forward kernel: redo it here)
+                xin = x2
+                x2, ln_mean, ln_rstd = N.layernorm(xin, ctx.ln[0], ctx.ln[1], ctx.ln[2])
             t = N.gemm_split(x2, p1f, bias=ctx.b1, amax=ctx.a1, groups=nb)      # another backward arithmetic: the pair below
         p2, p1 = (_packed(ctx.w[1], ctx.caches[1], "lin_bwd", True, terms), _packed(ctx.w[0], ctx.caches[0], "lin_bwd", True, terms))
         # fp16 x 2: ONE pass for the per-row maxima of g; the second product's operand u = g W2 (times GELU' <= 1.13) is
@@ -540,7 +548,24 @@ class _FrozenMlp(torch.autograd.Function):
             gx = N.gemm_split(N.gemm_split(g2, p2, groups=nb, **rows), p1, a_gelu_grad_of=t, groups=nb, **mul)
         else:
             gx = N.gemm_split(torch.ops.aten.gelu_backward(N.gemm_split(g2, p2, groups=nb, **rows), t), p1, groups=nb, **mul)
-        return gx.view(ctx.shape), None, None, None, None, (g if ctx.has_res else None), None, None, None
+        if ctx.kernel_fused and ctx.ln is not None:
+            gx = N.layernorm_backward(gx.contiguous(), xin, ctx.ln[0], ln_mean, ln_rstd)
+        return gx.view(ctx.shape), None, None, None, None, (g if ctx.has_res else None), None, None, None, None
+
+
+def _mlp_takes_layernorm(y, norm, w1, b1, w2, a1, a2):
+    """the block's LayerNorm can ride inside the fused MLP kernels (M8f): the conditions under which _FrozenMlp.forward takes
+    sea_mlp_fused_fwd, plus frozen, aligned LayerNorm parameters"""
+    from .. import _native as N
+    return (FUSE_LN_INTO_MLP and _terms() == 22 and int(FUSE_MLP) & 16 and a1 is not None and a2 is not None and a1.numel() == 1
+            and a2.numel() == 1 and b1 is not None and N.mlp_fused_ok(w2.shape[0], w1.shape[0]) and y.is_contiguous()
+            and y.data_ptr() % 16 == 0 and norm.weight is not None and norm.bias is not None
+            and not (norm.weight.requires_grad or norm.bias.requires_grad) and norm.weight.is_contiguous()
+            and norm.bias.is_contiguous() and norm.weight.data_ptr() % 16 == 0 and norm.bias.data_ptr() % 16 == 0
+            and USE_HIP_LAYERNORM and _bwd_terms(22) == 22)
+
+
+FUSE_LN_INTO_MLP = os.environ.get("SEA_MLP_FUSE_LN", "1") != "0"
 
 
 def _taps_major(conv: nn.Conv2d):
@@ -743,9 +768,15 @@ class Block(nn.Module):
                     with torch.no_grad():
                         cache.update(key=key, w=_stable(cache.get("w"), (w2 * g[:, None]).contiguous()),
                                      b=None if b2 is None else _stable(cache.get("b"), b2 * g))
+                gelu_ok = isinstance(self.act, nn.GELU) and self.act.approximate == "none"
+                if (gelu_ok and _mlp_fusable(y, self.pwconv1.weight, self.pwconv1.bias, cache["w"], cache["b"])
+                        and _mlp_takes_layernorm(y, self.norm, self.pwconv1.weight, self.pwconv1.bias, cache["w"], a1, a2)
+                        and xn.is_contiguous() and xn.data_ptr() % 16 == 0):
+                    # LayerNorm, both projections, GELU and the residual in ONE kernel per direction (M8f)
+                    return _FrozenMlp.apply(y, self.pwconv1.weight, self.pwconv1.bias, cache["w"], cache["b"], xn, gc, a1, a2,
+                                            (self.norm.weight, self.norm.bias, self.norm.eps)).permute(0, 3, 1, 2)
                 yn = self.norm(y)
-                if isinstance(self.act, nn.GELU) and self.act.approximate == "none" and _mlp_fusable(
-                        yn, self.pwconv1.weight, self.pwconv1.bias, cache["w"], cache["b"]):
+                if gelu_ok and _mlp_fusable(yn, self.pwconv1.weight, self.pwconv1.bias, cache["w"], cache["b"]):
                     # GELU, GELU' and the residual add in the GEMM epilogues
                     return _FrozenMlp.apply(yn, self.pwconv1.weight, self.pwconv1.bias, cache["w"], cache["b"], xn, gc, a1,
                                             a2).permute(0, 3, 1, 2)

@@ -85,6 +85,28 @@ def test_fused_mlp_gives_the_bits_of_the_two_gemm_form(N, C, M):
                        gx[:k])
 
 
+@pytest.mark.parametrize("C,M", [(96, 2048), (96, 333), (192, 1024), (192, 97)])
+def test_layernorm_inside_the_fused_mlp_gives_the_bits_of_the_layernorm_kernel(N, C, M):
+    """the block's LayerNorm in the kernels' prologue (and its input gradient in the backward's epilogue): the channel sums are
+    taken in the order of sea_layernorm_fwd / _bwd, so the result equals LayerNorm kernel + fused MLP bit for bit"""
+    x, w1, b1, w2, b2, res, gy = _case(C, M, 7 * C + M)
+    g = torch.Generator(device="cuda").manual_seed(C)
+    x = x * (torch.rand(M, 1, generator=g, device="cuda") * 4 + 0.1) + torch.randn(M, 1, generator=g, device="cuda")   # rows with their own mean / scale
+    lw = torch.rand(C, generator=g, device="cuda") + 0.5
+    lb = torch.randn(C, generator=g, device="cuda") * 0.1
+    eps = 1e-6
+    yn, mean, rstd = N.layernorm(x, lw, lb, eps)
+    a1, a2, mul = _bounds(yn, w1, b1, w2)
+    P = lambda w, tr=False: N.gemm_split_pack(w, trans=tr, terms=22)       # noqa: E731
+    y_ref = N.mlp_fused_forward(yn, P(w1), b1, P(w2), b2, res, a1, a2)
+    y = N.mlp_fused_forward(x, P(w1), b1, P(w2), b2, res, a1, a2, ln=(lw, lb, eps))
+    assert torch.equal(y, y_ref), (y - y_ref).abs().max().item()
+    gyn = N.mlp_fused_backward(gy, yn, P(w1), b1, P(w2, True), P(w1, True), a1, mul)
+    gx_ref = N.layernorm_backward(gyn, x, lw, mean, rstd)
+    gx = N.mlp_fused_backward(gy, x, P(w1), b1, P(w2, True), P(w1, True), a1, mul, ln=(lw, lb, eps))
+    assert torch.equal(gx, gx_ref), (gx - gx_ref).abs().max().item()
+
+
 @pytest.mark.parametrize("C", [96, 192])
 def test_fused_mlp_gradient_rows_over_many_orders_of_magnitude(N, C):
     """the per-row scales of the gradient operand come from the registers that hold the row: rows spread over 2^60 keep their
@@ -138,18 +160,20 @@ def test_block_takes_the_fused_kernels_and_keeps_its_bits(N, C, hw):
     calls = []
     real = N.mlp_fused_forward
     N.mlp_fused_forward = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
-    old = N.USE_MLP_FUSED
+    old = (N.USE_MLP_FUSED, M.FUSE_LN_INTO_MLP)
     try:
-        for fused in (False, True):
-            N.USE_MLP_FUSED = fused
+        # the two-GEMM form; the fused MLP behind the LayerNorm kernel; LayerNorm + MLP in one kernel (the default)
+        for fused, ln_in in ((False, False), (True, False), (True, True)):
+            N.USE_MLP_FUSED, M.FUSE_LN_INTO_MLP = fused, ln_in
             xi = x.clone().requires_grad_(True)
             y = blk(xi)
             (gx,) = torch.autograd.grad(y, xi, gy)
             outs.append((y.detach().clone(), gx.clone()))
     finally:
-        N.USE_MLP_FUSED, N.mlp_fused_forward = old, real
-    assert len(calls) == 1, "the Block did not reach the fused kernel"
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        (N.USE_MLP_FUSED, M.FUSE_LN_INTO_MLP), N.mlp_fused_forward = old, real
+    assert len(calls) == 2, "the Block did not reach the fused kernel"
+    for o in outs[1:]:
+        assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1])
 
 
 def test_branch_free_gelu_is_the_library_gelu_for_every_float(N):

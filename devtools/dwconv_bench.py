@@ -47,8 +47,11 @@ def main():
             ya = run(xs[0], 0)
             same = torch.equal(ya, run(xs[0], 2))
             mb = 8 * xs[0].numel() / 1e6
-            same = same and torch.equal(ya, run(xs[0], 4))
-            for order, f in (("2row", 8), ("1row", 4), ("1r-lin", 6)):
+            same = same and torch.equal(ya, run(xs[0], 4)) and torch.equal(ya, run(xs[0], 16)) and torch.equal(ya, run(xs[0], 20))
+            # (bit 16: the plain kernels; without it the software-pipelined ones of round 6)
+            same = same and torch.equal(ya, run(xs[0], 32 + 8)) and torch.equal(ya, run(xs[0], 32 + 4)) and torch.equal(ya, run(xs[0], 8))
+            # (bit 32: filter rows from global memory instead of LDS)
+            for order, f in (("pipe2", 8), ("pipe1", 4), ("p2-glb", 40), ("p1-glb", 36), ("2row", 24), ("1row", 20)):
                 hot = timed(lambda: run(xs[0], f), 20)
 
                 def ring():

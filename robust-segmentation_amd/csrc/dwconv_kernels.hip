@@ -233,9 +233,165 @@ __global__ __launch_bounds__(256, 2) void dwconv7x7_nhwc_2row_kernel(const float
   }
 }
 
+// ---- software-pipelined variants for the ConvNeXt widths (CG = C / 4 a compile-time constant).
+// The two kernels above issue a row's loads, wait for them, then run its FMAs: one wave's chain is (latency + FMAs) x rows,
+// and with two waves per SIMD (the register budget) little of the latency is covered: 46.6 us for 96 channels at 128 x 128
+// where the VALU floor is 15 us and the HBM floor 17 us; 16 us for 384 channels at 32 x 32 (floors 2.5 / 4.4 us).  Here the
+// loop is unrolled over the filter rows with TWO input-row buffers and TWO filter-row buffers: the next input row is requested
+// before the current one is consumed, the next filter row as soon as its registers fall free.  Borders cost nothing: every
+// input row gets its own buffer descriptor (num_records = the row's bytes, or 0 for a row outside the image), so a pixel
+// right of the row or a whole missing row reads as zeros; only the three pixels LEFT of a row's first strip need a select on
+// the lane offset.  Same accumulation order per output as the kernels above (bias; ky ascending; kx ascending): same bits.
+typedef float dw_f4 __attribute__((ext_vector_type(4)));
+
+// WLDS: the block copies the 49 x CG filter into LDS first (flipped for backward-data) and takes its filter rows from there:
+// they are a third of the loads (7 next to 14 per row), the same for every strip, and the vector L1 path (64 B/clk per CU)
+// is the tighter bound of this kernel next to the VALU (CG <= 96: 18 / 37 / 74 KB, two blocks per CU).
+template <int CG, int ROWS, bool FLIP, bool BIAS, bool ADD, bool WLDS>
+__global__ __launch_bounds__(256, 2) void dwconv7x7_nhwc_pipe_kernel(const float4* __restrict__ x, const float4* __restrict__ wt,
+                                                                     const float4* __restrict__ bias,
+                                                                     const float4* __restrict__ addend, float4* __restrict__ y,
+                                                                     int H, int W, int gx, int HP, int units, int per_xcd) {
+  constexpr int SPB = 256 / CG, NIN = DWN_STRIP + DW_K - 1;
+  constexpr uint32_t OOB = 0x40000000u;
+  extern __shared__ __attribute__((aligned(16))) char dw_smem[];
+  const int cg = threadIdx.x % CG, ps = threadIdx.x / CG;
+  const int u = per_xcd ? (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  if (u >= units) return;
+  if constexpr (WLDS) {
+    for (int i = threadIdx.x; i < DW_K * DW_K * CG; i += 256) {
+      const int tap = i / CG, c = i - tap * CG;
+      *(float4*)(dw_smem + i * 16) = wt[(FLIP ? (DW_K * DW_K - 1 - tap) : tap) * CG + c];
+    }
+    __syncthreads();
+  }
+  if (ps >= SPB) return;
+  const int bx = u % gx, op = (u / gx) % HP, b = u / (gx * HP);
+  const int oy0 = op * ROWS;
+  const int ox0 = (bx * SPB + ps) * DWN_STRIP;
+  if (ox0 >= W) return;
+  const int row_bytes = W * CG * 16;
+  const char* const img = (const char*)(x + (int64_t)b * H * W * CG);
+  const uint32_t vbase = (uint32_t)((ox0 * CG + cg) * 16);
+  const float4* const wb = wt + cg;
+
+  dw_f4 in[2][NIN], w[2][DW_K];
+  auto load_input_row = [&](int iy, dw_f4 (&dst)[NIN]) __attribute__((always_inline)) {
+    const bool ok = iy >= 0 && iy < H;
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(img + (int64_t)(ok ? iy : 0) * row_bytes), 0, ok ? row_bytes : 0, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < NIN; ++j) {
+      uint32_t off;
+      if (j < DW_P)
+        off = ox0 > 0 ? vbase - (uint32_t)((DW_P - j) * CG * 16) : OOB;
+      else
+        off = vbase + (uint32_t)((j - DW_P) * CG * 16);
+      dst[j] = __builtin_bit_cast(dw_f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+    }
+  };
+  auto load_filter_row = [&](int ky, dw_f4 (&dst)[DW_K]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kx = 0; kx < DW_K; ++kx) {
+      const int tap = ky * DW_K + kx;
+      if constexpr (WLDS)
+        dst[kx] = *(const dw_f4*)(dw_smem + (tap * CG + cg) * 16);
+      else
+        dst[kx] = *(const dw_f4*)(wb + (FLIP ? (DW_K * DW_K - 1 - tap) : tap) * CG);
+    }
+  };
+  auto accumulate = [&](const dw_f4 (&src)[NIN], const dw_f4 (&f)[DW_K], dw_f4 (&acc)[DWN_STRIP]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kx = 0; kx < DW_K; ++kx)
+#pragma unroll
+      for (int j = 0; j < DWN_STRIP; ++j) acc[j] = __builtin_elementwise_fma(src[j + kx], f[kx], acc[j]);
+  };
+
+  dw_f4 acc0[DWN_STRIP], acc1[ROWS == 2 ? DWN_STRIP : 1];
+  load_input_row(oy0 - DW_P, in[0]);
+  load_filter_row(0, w[0]);
+  {
+    const dw_f4 b0 = BIAS ? *(const dw_f4*)(bias + cg) : dw_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < DWN_STRIP; ++j) acc0[j] = b0;
+    if constexpr (ROWS == 2) {
+#pragma unroll
+      for (int j = 0; j < DWN_STRIP; ++j) acc1[j] = b0;
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (ROWS == 2) {
+    // r = 0 .. 7: input row oy0 - 3 + r feeds output row oy0 with filter row r and output row oy0 + 1 with filter row r - 1
+#pragma unroll
+    for (int r = 0; r < DW_K + 1; ++r) {
+      const int cur = r & 1;
+      if (r < DW_K) load_input_row(oy0 - DW_P + r + 1, in[cur ^ 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (r >= 1) accumulate(in[cur], w[cur ^ 1], acc1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (r + 1 < DW_K) load_filter_row(r + 1, w[cur ^ 1]);          // (filter row r - 1 is done with)
+      __builtin_amdgcn_sched_barrier(0);
+      if (r < DW_K) accumulate(in[cur], w[cur], acc0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < DW_K; ++r) {
+      const int cur = r & 1;
+      if (r + 1 < DW_K) {
+        load_input_row(oy0 - DW_P + r + 1, in[cur ^ 1]);
+        load_filter_row(r + 1, w[cur ^ 1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      accumulate(in[cur], w[cur], acc0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // (the launcher sends only W % 8 == 0 and, for two rows, even H here: the stores are unconditional.  Guarded stores would
+  // let the compiler sink each output's whole FMA chain into its guard's block -- past every load of the loop above)
+  const int64_t ro = ((int64_t)b * H + oy0) * W * CG + cg;
+  dw_f4* const yr = (dw_f4*)(y + ro);
+#pragma unroll
+  for (int j = 0; j < DWN_STRIP; ++j) {
+    if (ADD) acc0[j] += *(const dw_f4*)(addend + ro + (int64_t)(ox0 + j) * CG);  // y = conv + addend (added last)
+    yr[(int64_t)(ox0 + j) * CG] = acc0[j];
+  }
+  if constexpr (ROWS == 2) {
+#pragma unroll
+    for (int j = 0; j < DWN_STRIP; ++j) {
+      if (ADD) acc1[j] += *(const dw_f4*)(addend + ro + ((int64_t)W + ox0 + j) * CG);
+      yr[((int64_t)W + ox0 + j) * CG] = acc1[j];
+    }
+  }
+}
+
 }  // namespace sea
 
 using namespace sea;
+
+template <int CG, int ROWS, bool FLIP, bool BIAS, bool ADD>
+static void dw_pipe_launch(dim3 grid, hipStream_t s, const float4* x4, const float4* w4, const float4* b4, const float4* a4,
+                           float4* y4, int H, int W, int gx, int HP, int units, int per_xcd, bool wlds) {
+  if constexpr (CG <= 96) {
+    if (wlds) {
+      constexpr int lds = DW_K * DW_K * CG * 16;
+      auto k = dwconv7x7_nhwc_pipe_kernel<CG, ROWS, FLIP, BIAS, ADD, true>;
+      if constexpr (lds > 65536) {
+        static bool attr_set_dev[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (!attr_set_dev[dev & 63]) {
+          (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+          attr_set_dev[dev & 63] = true;
+        }
+      }
+      hipLaunchKernelGGL(k, grid, dim3(256), (size_t)lds, s, x4, w4, b4, a4, y4, H, W, gx, HP, units, per_xcd);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((dwconv7x7_nhwc_pipe_kernel<CG, ROWS, FLIP, BIAS, ADD, false>), grid, dim3(256), 0, s, x4, w4, b4, a4, y4, H, W,
+                     gx, HP, units, per_xcd);
+}
 
 // A/B switches of the NHWC depthwise launcher (development only; unset = shipped dispatch).  Looked up per call (one
 // getenv, ~0.1 us next to a 5 us launch) so that one process can compare variants.
@@ -266,7 +422,11 @@ extern "C" int sea_dwconv7x7_nhwc_add(const float* x, const float* wt, const flo
   // 64^2: 21 vs 23 us) and lose on the small ones, where halving the number of blocks costs more than the loads saved
   // (768 ch 16^2: 11.2 vs 8.7 us); profiles/r2_dwconv_rows_ab.log.
   const int ab = dwconv_ab_switches();
-  const bool two_rows = !(ab & 4) && H >= 2 && ((ab & 8) || (int64_t)H * W >= 4096);
+  const int CG0 = C / 4;
+  const bool pipe_ok = !(ab & 16) && (CG0 == 24 || CG0 == 48 || CG0 == 96 || CG0 == 192) && (int64_t)B * H * W * C * 4 < (1ll << 31) &&
+                       (W % DWN_STRIP) == 0;
+  // (the pipelined kernels keep winning with two rows down to 32 x 32: 12.3 / 10.2 us against 13.7 / 13.4)
+  const bool two_rows = !(ab & 4) && H >= 2 && ((ab & 8) || (int64_t)H * W >= (pipe_ok && (H % 2) == 0 ? 1024 : 4096));
   const int HP = two_rows ? (H + 1) / 2 : H;
   const int64_t units64 = (int64_t)gx * HP * B;
   SEA_CHECK_ARG(units64 < (1ll << 30));
@@ -282,6 +442,39 @@ extern "C" int sea_dwconv7x7_nhwc_add(const float* x, const float* wt, const flo
       hipLaunchKernelGGL((dwconv7x7_nhwc_kernel<F, BI, AD>), grid, block, 0, s, x4, w4, b4, a4, y4, CG, H, W, spb, gx,   \
                          units, per_xcd);                                                                               \
   } while (0)
+  // software-pipelined kernels for the ConvNeXt widths (bit 4, value 16, of SEA_DWCONV_AB: the plain kernels instead)
+  const bool piped = pipe_ok && (!two_rows || (H % 2) == 0);
+#define SEA_DW_PIPE(CGV, F, BI, AD)                                                              \
+  do {                                                                                           \
+    if (two_rows)                                                                                \
+      dw_pipe_launch<CGV, 2, F, BI, AD>(grid, s, x4, w4, b4, a4, y4, H, W, gx, HP, units, per_xcd, wlds); \
+    else                                                                                         \
+      dw_pipe_launch<CGV, 1, F, BI, AD>(grid, s, x4, w4, b4, a4, y4, H, W, gx, HP, units, per_xcd, wlds); \
+  } while (0)
+  // filter rows from LDS only for one row per lane (35 vs 40 us at 96 x 128^2; with two rows the copy costs what it saves:
+  // profiles/r6_dwconv_pipe_ab.log); bit 5 (value 32) of SEA_DWCONV_AB: never, bit 6 (value 64): always
+  const bool wlds = !(ab & 32) && (!two_rows || (ab & 64));
+#define SEA_DW_PIPE_CG(F, BI, AD)                       \
+  do {                                                  \
+    if (CG == 24) SEA_DW_PIPE(24, F, BI, AD);           \
+    else if (CG == 48) SEA_DW_PIPE(48, F, BI, AD);      \
+    else if (CG == 96) SEA_DW_PIPE(96, F, BI, AD);      \
+    else SEA_DW_PIPE(192, F, BI, AD);                   \
+  } while (0)
+  if (piped) {
+    if (flip) {
+      if (addend) SEA_DW_PIPE_CG(true, false, true); else SEA_DW_PIPE_CG(true, false, false);
+    } else if (bias) {
+      SEA_DW_PIPE_CG(false, true, false);
+    } else if (addend) {
+      SEA_DW_PIPE_CG(false, false, true);
+    } else {
+      SEA_DW_PIPE_CG(false, false, false);
+    }
+    SEA_RETURN_LAST();
+  }
+#undef SEA_DW_PIPE_CG
+#undef SEA_DW_PIPE
   if (flip) {
     if (addend)
       SEA_DW_LAUNCH(true, false, true);

@@ -829,7 +829,7 @@ def test_convnext_block_fast_layout_path_matches_plain_path(N):
 
 
 @pytest.mark.parametrize("shape", [(2, 96, 64, 64), (1, 768, 16, 16), (2, 192, 33, 21), (1, 4, 7, 70), (2, 384, 32, 32),
-                                   (1, 8, 1, 9), (1, 8, 2, 5), (1, 12, 5, 128)])
+                                   (1, 8, 1, 9), (1, 8, 2, 5), (1, 12, 5, 128), (1, 192, 64, 64), (1, 96, 31, 40)])
 def test_dwconv7x7_nhwc_forward_and_backward_data(N, shape):
     import torch.nn.functional as F
     g = torch.Generator().manual_seed(shape[1] + 1)
@@ -856,10 +856,12 @@ def test_dwconv7x7_nhwc_forward_and_backward_data(N, shape):
     assert torch.equal(N.dwconv7x7_nhwc(gyn, dev(wt), None, flip=2, addend=skip), gx + skip)   # `flip` is a boolean
     with pytest.raises(N.SeaNativeError):
         N.dwconv7x7_nhwc(xn, dev(wt), dev(b), addend=skip)  # bias and addend are mutually exclusive
-    # the A/B switches of the launcher (SEA_DWCONV_AB: 2 = plain block order, 4 = one row per lane, 8 = force two rows)
+    # the A/B switches of the launcher (SEA_DWCONV_AB: 2 = plain block order, 4 = one row per lane, 8 = force two rows,
+    # 16 = the plain kernels instead of the software-pipelined ones of the ConvNeXt widths, 32 / 64 = their filter rows never /
+    # always through LDS)
     import os
     try:
-        for bits in (2, 4, 6, 8, 10):
+        for bits in (2, 4, 6, 8, 10, 16, 20, 24, 36, 40, 68, 72):
             os.environ["SEA_DWCONV_AB"] = str(bits)
             assert torch.equal(y, N.dwconv7x7_nhwc(xn, dev(wt), dev(b)))
             assert torch.equal(gx, N.dwconv7x7_nhwc(dev(gy.permute(0, 2, 3, 1).contiguous()), dev(wt), None, flip=True))

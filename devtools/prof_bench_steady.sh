@@ -11,4 +11,5 @@ f=$(ls /tmp/pb_$TAG/*/*_kernel_stats.csv | head -1)
 head -40 "$f" > gpurun_out/${TAG}_kernel_stats.csv
 k=$(ls /tmp/pb_$TAG/*/*_kernel_trace.csv | head -1)
 python3 devtools/trace_by_grid.py "$k" "" 0.5 > gpurun_out/${TAG}_by_grid.txt
+python3 devtools/trace_step_sequence.py "$k" > gpurun_out/${TAG}_step_sequence.txt 2>&1
 grep '"metric"' gpurun_out/${TAG}_bench.log | cut -c1-200

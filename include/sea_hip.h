@@ -492,6 +492,20 @@ int sea_gemm_split(const float* A, int64_t lda, const void* Wp, float* C, int64_
                    int N, int K, int terms, int batch, int64_t strideA, int64_t strideW_bytes, int64_t strideC,
                    void* stream);
 /* ------------------------------------------------------------------------------------------------
+ * M9   the decode head's classifier, a 1 x 1 convolution onto a SMALL number of classes (semseg/models/uperforseg.py:262
+ *      `cls_seg`; reference autograd for the input gradient), forward and input gradient for frozen weights, on
+ *      v_mfma_f32_32x32x2_f32 (exact fp32 products).  Replaces torch.matmul (hipBLASLt) on these shapes.
+ *   y / gy: (B P, K) fp32 NHWC rows, contiguous, 16-byte aligned; W: (cls, K) contiguous, 16-byte aligned; bias (cls) or NULL;
+ *   out / g: (B, cls, P) fp32 NCHW, contiguous.  Shapes: sea_classifier_supported (P % 32 == 0, K % 64 == 0, K <= 1024,
+ *   cls <= 32); anything else -> SEA_ERR_ARG.
+ *   backward, optional: gate (layout of gy) and gate_scale (K): gy = gate > 0 ? gy * gate_scale[k] : 0, the backward of the
+ *   ReLU(scale z + shift) that produced y (uperforseg.py:296-304 with the eval-mode BatchNorm folded) -- bit for bit
+ *   sea_gate_scale applied to the stored gradient, without the 0.8 GB pass. */
+int sea_classifier_supported(int P, int K, int cls);
+int sea_classifier_fwd(const float* y, const float* W, const float* bias, float* out, int B, int P, int K, int cls, void* stream);
+int sea_classifier_bwd(const float* g, const float* W, float* gy, int B, int P, int K, int cls, const float* gate,
+                       const float* gate_scale, void* stream);
+/* ------------------------------------------------------------------------------------------------
  * M8f  the MLP of a ConvNeXt block, y = res + W2 GELU(W1 x + b1) + b2 (semseg/models/backbones/convnext_orig.py:77-79:
  *      pwconv1 -> act -> pwconv2 with the layer scale folded into W2; reference autograd for the input gradient), as ONE
  *      kernel per direction.  Replaces, bit for bit, the pair of sea_gemm_split_fused launches (a_gelu / a_gelu_grad_of

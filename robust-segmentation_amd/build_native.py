@@ -47,6 +47,7 @@ SOURCES = [
     ("gemm_split_big.hip", ["-fno-slp-vectorize"]),
     ("gemm_split_pp.hip", ["-fno-slp-vectorize"]),   # (packed f32 VALU beside MFMAs costs issue time: MI355X guide)
     ("mlp_fused.hip", ["-fno-slp-vectorize"]),
+    ("classifier.hip", []),
     ("greedy_host.cpp", ["-ffp-contract=off"]),
     ("api_misc.cpp", []),
 ]

@@ -98,6 +98,9 @@ _SIGS = {
     "sea_gemm_split_pack": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp]),
     "sea_gemm_split": (_i, [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _vp]),
     "sea_mlp_fused_supported": (_i, [_i, _i]),
+    "sea_classifier_supported": (_i, [_i, _i, _i]),
+    "sea_classifier_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "sea_classifier_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "sea_probe_gelu_mismatches": (_i, [_vp, _vp]),
     "sea_probe_ln_rows": (_i, [_vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp]),
     "sea_mlp_fused_stamps": (_i, [_i, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -679,6 +682,10 @@ def wino_filter(weight, m: int, flip: bool):
     return U
 
 
+# fewest Winograd tiles (rows of each of the 36 / 16 Winograd-domain products) that go through M8; below: hipBLASLt's batched fp32 GEMM
+WINO_SPLIT_MIN_TILES = int(os.environ.get("SEA_WINO_SPLIT_MIN_TILES", "128"))
+
+
 def wino_conv3x3_cl(x, U, m: int, bias=None, scale=None, relu: bool = False, gate=None, gate_scale=None,
                     addend=None, gemm_terms: int = 0):
     """3x3 / stride 1 / pad 1 convolution of a channels_last (B,Cin,H,W) tensor (or channel slice) -- or of the
@@ -704,7 +711,7 @@ def wino_conv3x3_cl(x, U, m: int, bias=None, scale=None, relu: bool = False, gat
     T = L.sea_wino_tiles(B, H, W, m)
     V = torch.empty(A2, T, Cin, dtype=torch.float32, device=xs[0].device)
     off = 0
-    use_split = gemm_terms in (1, 2, 3, 22) and Cin % 32 == 0 and T >= 256
+    use_split = gemm_terms in (1, 2, 3, 22) and Cin % 32 == 0 and T >= WINO_SPLIT_MIN_TILES
     # fp16 x 2: one scale word per tile (= per row of the Winograd-domain GEMMs), filled by the transform itself
     v_amax = (torch.zeros(T, dtype=torch.int32, device=xs[0].device)
               if (use_split and gemm_terms == 22 and AMAX_FROM_PRODUCERS) else None)
@@ -956,6 +963,46 @@ def gemm_split_pack(W, trans: bool = False, terms: int = 3) -> PackedWeight:
 
 # ------------------------------------------------------------------------------------------------ M8f
 USE_MLP_FUSED = os.environ.get("SEA_MLP_FUSED", "1") != "0"
+USE_CLASSIFIER = os.environ.get("SEA_CLASSIFIER", "1") != "0"
+
+
+def classifier_ok(P: int, K: int, cls: int) -> bool:
+    """the head's 1 x 1 classifier has its own kernels for this shape (M9: at most 32 classes)"""
+    return bool(USE_CLASSIFIER and lib().sea_classifier_supported(int(P), int(K), int(cls)))
+
+
+def classifier_forward(y_rows, w2d, bias, B: int, P: int):
+    """logits (B, cls, P) NCHW = W (cls, K) . y^T for y_rows (B P, K) fp32 NHWC rows (sea_classifier_fwd)"""
+    _dev(y_rows, w2d, bias)
+    cls, K = w2d.shape
+    if (y_rows.dtype != torch.float32 or y_rows.shape != (B * P, K) or not y_rows.is_contiguous() or y_rows.data_ptr() % 16
+            or w2d.dtype != torch.float32 or not w2d.is_contiguous() or w2d.data_ptr() % 16
+            or (bias is not None and (bias.dtype != torch.float32 or bias.numel() != cls or not bias.is_contiguous()))):
+        raise SeaNativeError("classifier_forward: y (B P, K) / W (cls, K) must be contiguous, 16-byte aligned float32")
+    out = torch.empty((B, cls, P), dtype=torch.float32, device=y_rows.device)
+    _check(lib().sea_classifier_fwd(_p(y_rows), _p(w2d), _p(bias), _p(out), B, P, K, cls, _stream()), "sea_classifier_fwd")
+    return out
+
+
+def classifier_backward(g, w2d, gate=None, gate_scale=None):
+    """gy (B P, K) NHWC rows = g^T (B, P, cls) . W (cls, K) for the NCHW logit gradient g (B, cls, P) (sea_classifier_bwd).
+    ``gate`` (B P, K) with ``gate_scale`` (K): the result is (gate > 0 ? gy * gate_scale : 0) -- ``gate_scale`` of the
+    gradient, applied on the way out."""
+    _dev(g, w2d, gate, gate_scale)
+    cls, K = w2d.shape
+    if (gate is None) != (gate_scale is None):
+        raise SeaNativeError("classifier_backward: gate and gate_scale come together")
+    if gate is not None and (gate.dtype != torch.float32 or gate.dim() != 2 or gate.shape[1] != K or not gate.is_contiguous()
+                             or gate_scale.dtype != torch.float32 or gate_scale.numel() != K or not gate_scale.is_contiguous()
+                             or g.dim() != 3 or gate.shape[0] != g.shape[0] * g.shape[2]):
+        raise SeaNativeError("classifier_backward: gate must be contiguous float32 (B P, K) rows, gate_scale (K)")
+    if (g.dtype != torch.float32 or g.dim() != 3 or g.shape[1] != cls or not g.is_contiguous()
+            or w2d.dtype != torch.float32 or not w2d.is_contiguous() or w2d.data_ptr() % 16):
+        raise SeaNativeError("classifier_backward: g (B, cls, P) / W (cls, K) must be contiguous float32")
+    B, _, P = g.shape
+    gy = torch.empty((B * P, K), dtype=torch.float32, device=g.device)
+    _check(lib().sea_classifier_bwd(_p(g), _p(w2d), _p(gy), B, P, K, cls, _p(gate), _p(gate_scale), _stream()), "sea_classifier_bwd")
+    return gy
 
 
 def mlp_fused_ok(C: int, H: int) -> bool:

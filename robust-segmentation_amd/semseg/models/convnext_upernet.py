@@ -1198,41 +1198,72 @@ USE_FUSED_FPN_BOTTLENECK = True
 LOWRES_MIN_FACTOR = 3.0
 
 
+def _fpn_bottleneck_forward(ctx, m, cache, weight, scale, shift, fs, first_grad_index):
+    """forward of _FpnBottleneck / _FpnBottleneckClassify: returns y = relu(bn(conv3x3(cat(...)))) and fills ``ctx`` for
+    _fpn_bottleneck_backward; ``first_grad_index`` = position of fs[0] among the Function's inputs"""
+    from .. import _native as N
+    B, (H, W), Cout = fs[0].shape[0], fs[0].shape[2:], weight.shape[0]
+    chans = [f.shape[1] for f in fs]
+    offs = [sum(chans[:i]) for i in range(len(fs))]
+    hi = [i for i, f in enumerate(fs) if i == 0 or H / f.shape[2] < LOWRES_MIN_FACTOR or W / f.shape[3] < LOWRES_MIN_FACTOR]
+    lo = [i for i in range(len(fs)) if i not in hi]
+    key = (_tkey(weight), m, tuple(hi), tuple(chans))
+    if cache.get("fpn_key") != key:
+        w_hi = torch.cat([weight[:, offs[i]:offs[i] + chans[i]] for i in hi], 1).contiguous()
+        cache.update(fpn_key=key, fpn_fwd=_stable(cache.get("fpn_fwd"), N.wino_filter(w_hi, m, False)),
+                     fpn_bwd=_stable(cache.get("fpn_bwd"), N.wino_filter(w_hi, m, True)),
+                     fpn_lo=_stable(cache.get("fpn_lo"), [weight[:, offs[i]:offs[i] + chans[i]].permute(2, 3, 0, 1)
+                                                          .reshape(9 * Cout, chans[i]).contiguous() for i in lo]))
+        # rows of fpn_lo (tap, cout): F.linear -> (B,h,w,9*Cout)
+    # the fine inputs are transformed side by side into the Winograd domain: no concatenation buffer
+    xs = [_dense_cl(fs[i]) if tuple(fs[i].shape[2:]) == (H, W) else N.upsample_bilinear_cl(_dense_cl(fs[i]), (H, W))
+          for i in hi]
+    extra = None
+    for j, i in enumerate(lo):
+        f = _dense_cl(fs[i])
+        G = _frozen_mm(f.permute(0, 2, 3, 1).reshape(-1, f.shape[1]), cache["fpn_lo"][j], cache,
+                       f"fpn_lo_fwd{j}", groups=B).view(B, f.shape[2], f.shape[3], 9, Cout)
+        extra = N.tap_gather(G, (H, W), extra)
+    ctx.terms = _terms()
+    y = N.wino_conv3x3_cl(xs, cache["fpn_fwd"], m, bias=shift, scale=scale, relu=True, addend=extra,
+                          gemm_terms=ctx.terms)
+    ctx.cache, ctx.m, ctx.hi, ctx.lo, ctx.chans, ctx.first = cache, m, hi, lo, chans, first_grad_index
+    ctx.shapes = [tuple(f.shape) for f in fs]
+    return y
+
+
+def _fpn_bottleneck_backward(ctx, gz, y):
+    """input gradients of the FPN bottleneck from gz = the gradient at the convolution's output (the ReLU gate and the folded
+    BatchNorm scale already applied); y: the saved output (its shape)"""
+    from .. import _native as N
+    cache, chans, shapes = ctx.cache, ctx.chans, ctx.shapes
+    B, _, H, W = y.shape
+    grads = [None] * len(shapes)
+    if any(ctx.needs_input_grad[ctx.first + i] for i in ctx.hi):
+        gbuf = N.wino_conv3x3_cl(gz, cache["fpn_bwd"], ctx.m, gemm_terms=_bwd_terms(ctx.terms))
+        off = 0
+        for i in ctx.hi:
+            sl = gbuf[:, off:off + chans[i]]
+            off += chans[i]
+            if ctx.needs_input_grad[ctx.first + i]:
+                grads[i] = sl if shapes[i][2:] == (H, W) else N.upsample_bilinear_backward_cl(sl, shapes[i][2:])
+    for j, i in enumerate(ctx.lo):
+        if ctx.needs_input_grad[ctx.first + i]:
+            h, w = shapes[i][2:]
+            dG = N.tap_gather_backward(gz, (h, w))
+            grads[i] = _frozen_mm(dG.view(B * h * w, -1), cache["fpn_lo"][j], cache, f"fpn_lo_bwd{j}", trans=True,
+                                  terms=_bwd_terms(ctx.terms), groups=B, row_amax=True).view(B, h, w, chans[i]).permute(0, 3, 1, 2)
+    return grads
+
+
 class _FpnBottleneck(torch.autograd.Function):
     """relu(bn(conv3x3(cat([f0, up(f1), ..., up(fn)])))) for frozen weights / eval-mode BatchNorm, input grads only."""
 
     @staticmethod
     @_fp32_fwd
     def forward(ctx, m, cache, weight, scale, shift, *fs):
-        from .. import _native as N
-        B, (H, W), Cout = fs[0].shape[0], fs[0].shape[2:], weight.shape[0]
-        chans = [f.shape[1] for f in fs]
-        offs = [sum(chans[:i]) for i in range(len(fs))]
-        hi = [i for i, f in enumerate(fs) if i == 0 or H / f.shape[2] < LOWRES_MIN_FACTOR or W / f.shape[3] < LOWRES_MIN_FACTOR]
-        lo = [i for i in range(len(fs)) if i not in hi]
-        key = (_tkey(weight), m, tuple(hi), tuple(chans))
-        if cache.get("fpn_key") != key:
-            w_hi = torch.cat([weight[:, offs[i]:offs[i] + chans[i]] for i in hi], 1).contiguous()
-            cache.update(fpn_key=key, fpn_fwd=_stable(cache.get("fpn_fwd"), N.wino_filter(w_hi, m, False)),
-                         fpn_bwd=_stable(cache.get("fpn_bwd"), N.wino_filter(w_hi, m, True)),
-                         fpn_lo=_stable(cache.get("fpn_lo"), [weight[:, offs[i]:offs[i] + chans[i]].permute(2, 3, 0, 1)
-                                                              .reshape(9 * Cout, chans[i]).contiguous() for i in lo]))
-            # rows of fpn_lo (tap, cout): F.linear -> (B,h,w,9*Cout)
-        # the fine inputs are transformed side by side into the Winograd domain: no concatenation buffer
-        xs = [_dense_cl(fs[i]) if tuple(fs[i].shape[2:]) == (H, W) else N.upsample_bilinear_cl(_dense_cl(fs[i]), (H, W))
-              for i in hi]
-        extra = None
-        for j, i in enumerate(lo):
-            f = _dense_cl(fs[i])
-            G = _frozen_mm(f.permute(0, 2, 3, 1).reshape(-1, f.shape[1]), cache["fpn_lo"][j], cache,
-                           f"fpn_lo_fwd{j}", groups=B).view(B, f.shape[2], f.shape[3], 9, Cout)
-            extra = N.tap_gather(G, (H, W), extra)
-        ctx.terms = _terms()
-        y = N.wino_conv3x3_cl(xs, cache["fpn_fwd"], m, bias=shift, scale=scale, relu=True, addend=extra,
-                              gemm_terms=ctx.terms)
+        y = _fpn_bottleneck_forward(ctx, m, cache, weight, scale, shift, fs, 5)
         ctx.save_for_backward(y, scale)
-        ctx.cache, ctx.m, ctx.hi, ctx.lo, ctx.chans = cache, m, hi, lo, chans
-        ctx.shapes = [tuple(f.shape) for f in fs]
         return y
 
     @staticmethod
@@ -1240,25 +1271,35 @@ class _FpnBottleneck(torch.autograd.Function):
     def backward(ctx, gy):
         from .. import _native as N
         y, scale = ctx.saved_tensors
-        cache, chans, shapes = ctx.cache, ctx.chans, ctx.shapes
-        B, _, H, W = y.shape
         gz = N.gate_scale(_dense_cl(gy), y, scale)
-        grads = [None] * len(shapes)
-        if any(ctx.needs_input_grad[5 + i] for i in ctx.hi):
-            gbuf = N.wino_conv3x3_cl(gz, cache["fpn_bwd"], ctx.m, gemm_terms=_bwd_terms(ctx.terms))
-            off = 0
-            for i in ctx.hi:
-                sl = gbuf[:, off:off + chans[i]]
-                off += chans[i]
-                if ctx.needs_input_grad[5 + i]:
-                    grads[i] = sl if shapes[i][2:] == (H, W) else N.upsample_bilinear_backward_cl(sl, shapes[i][2:])
-        for j, i in enumerate(ctx.lo):
-            if ctx.needs_input_grad[5 + i]:
-                h, w = shapes[i][2:]
-                dG = N.tap_gather_backward(gz, (h, w))
-                grads[i] = _frozen_mm(dG.view(B * h * w, -1), cache["fpn_lo"][j], cache, f"fpn_lo_bwd{j}", trans=True,
-                                      terms=_bwd_terms(ctx.terms), groups=B, row_amax=True).view(B, h, w, chans[i]).permute(0, 3, 1, 2)
-        return (None, None, None, None, None, *grads)
+        return (None, None, None, None, None, *_fpn_bottleneck_backward(ctx, gz, y))
+
+
+class _FpnBottleneckClassify(torch.autograd.Function):
+    """_FpnBottleneck followed by the head's classifier (uperforseg.py:296-304 + 262) as ONE autograd node, for at most 32
+    classes (M9): the classifier's input-gradient kernel applies the bottleneck's ReLU gate and BatchNorm scale on the way
+    out, so the 0.8 GB gate pass between the two backward steps disappears; same bits as the two nodes."""
+
+    @staticmethod
+    @_fp32_fwd
+    def forward(ctx, m, cache, weight, scale, shift, cls_w2d, cls_bias, *fs):
+        from .. import _native as N
+        y = _fpn_bottleneck_forward(ctx, m, cache, weight, scale, shift, fs, 7)
+        B, Cout, H, W = y.shape
+        ctx.save_for_backward(y, scale)
+        ctx.cls_w2d = cls_w2d
+        return N.classifier_forward(y.permute(0, 2, 3, 1).reshape(B * H * W, Cout), cls_w2d, cls_bias, B, H * W).view(B, -1, H, W)
+
+    @staticmethod
+    @_fp32_bwd
+    def backward(ctx, g):
+        from .. import _native as N
+        y, scale = ctx.saved_tensors
+        B, Cout, H, W = y.shape
+        gz = N.classifier_backward(g.reshape(B, g.shape[1], H * W).contiguous(), ctx.cls_w2d,
+                                   gate=y.permute(0, 2, 3, 1).reshape(B * H * W, Cout), gate_scale=scale)
+        gz = gz.view(B, H, W, Cout).permute(0, 3, 1, 2)
+        return (None, None, None, None, None, None, None, *_fpn_bottleneck_backward(ctx, gz, y))
 
 
 def _fpn_fusable(mod, outs):
@@ -1330,19 +1371,40 @@ class _ClassifierGemm(torch.autograd.Function):
     @staticmethod
     @_fp32_fwd
     def forward(ctx, y, w2d, bias):
+        from .. import _native as N
         B, Cin, H, W = y.shape
+        ctx.w2d, ctx.shape = w2d, (B, Cin, H, W)
+        ctx.own = N.classifier_ok(H * W, Cin, w2d.shape[0]) and w2d.is_contiguous() and (bias is None or bias.is_contiguous())
+        if ctx.own:     # M9: at most 32 classes on the fp32 matrix cores, y read once (csrc/classifier.hip)
+            rows = y.permute(0, 2, 3, 1).reshape(B * H * W, Cin)
+            return N.classifier_forward(rows, w2d, bias, B, H * W).view(B, w2d.shape[0], H, W)
         out = torch.matmul(w2d, y.permute(0, 2, 3, 1).reshape(B, H * W, Cin).transpose(1, 2))
         if bias is not None:
             out += bias.view(1, -1, 1)
-        ctx.w2d, ctx.shape = w2d, (B, Cin, H, W)
         return out.view(B, w2d.shape[0], H, W)
 
     @staticmethod
     @_fp32_bwd
     def backward(ctx, g):
+        from .. import _native as N
         B, Cin, H, W = ctx.shape
-        gy = torch.matmul(g.reshape(B, g.shape[1], H * W).transpose(1, 2), ctx.w2d)      # (B, P, Cin) contiguous
+        if ctx.own:
+            gy = N.classifier_backward(g.reshape(B, g.shape[1], H * W).contiguous(), ctx.w2d)
+        else:
+            gy = torch.matmul(g.reshape(B, g.shape[1], H * W).transpose(1, 2), ctx.w2d)      # (B, P, Cin) contiguous
         return gy.view(B, H, W, Cin).permute(0, 3, 1, 2), None, None
+
+
+FUSE_CLASSIFIER_GATE = os.environ.get("SEA_FUSE_CLS_GATE", "1") != "0"   # A/B: _FpnBottleneckClassify
+
+
+def _classifier_fusable(conv: nn.Conv2d, cin, f0):
+    """the classifier behind the fused FPN bottleneck can ride in its autograd node (M9 kernels, frozen fp32 weights)"""
+    from .. import _native as N
+    return (FUSE_CLASSIFIER_GATE and conv.kernel_size == (1, 1) and conv.in_channels == cin and not torch.is_autocast_enabled()
+            and conv.weight.dtype == torch.float32 and not conv.weight.requires_grad
+            and (conv.bias is None or not conv.bias.requires_grad) and conv.weight.is_contiguous()
+            and N.classifier_ok(f0.shape[2] * f0.shape[3], cin, conv.out_channels))
 
 
 def _classify(conv: nn.Conv2d, y):
@@ -1384,6 +1446,10 @@ class UperNetHead(nn.Module):
             if not hasattr(neck, "_wino_cache"):
                 object.__setattr__(neck, "_wino_cache", {})
             scale, shift = _folded_bn(neck.batch_norm, None, neck._wino_cache)
+            cls = self.classifier
+            if _classifier_fusable(cls, neck.conv.out_channels, outs[0]):
+                return _FpnBottleneckClassify.apply(WINOGRAD_TILE, neck._wino_cache, neck.conv.weight, scale, shift,
+                                                    cls.weight.view(cls.out_channels, -1), cls.bias, *outs)
             y = _FpnBottleneck.apply(WINOGRAD_TILE, neck._wino_cache, neck.conv.weight, scale, shift, *outs)
         else:
             y = neck(_up_cat(outs, outs[0].shape[2:]))

@@ -176,6 +176,92 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
   }
 }
 
+// The same transform with FOUR channels per lane (16-byte accesses: a wave-load covers 1 KB instead of 512 B of the vector
+// memory path, which bounds this kernel -- most of all with the gate prologue, whose second input doubles the loads).  The
+// patch is consumed column by column (six loads, then that column of tmp = B^T d) so that only tmp (36 x 4 registers) stays
+// live; same axpy order per element as above: same bits.
+template <int M, int VEC>
+__global__ __launch_bounds__(256) void wino_input_cols_kernel(const float* __restrict__ x, const float* __restrict__ gate,
+                                                              const float* __restrict__ scale, float* __restrict__ V, int C,
+                                                              int H, int W, int nTh, int nTw, int64_t T, int64_t total,
+                                                              int64_t xps, int64_t vts, int xcd, Divs3 dv,
+                                                              uint32_t* __restrict__ amax_out) {
+  constexpr int A = M + 2;
+  const bool fast = total < kFastIndexLimit;
+  const IndexRange rg = xcd_range(total, xcd);
+  for (int64_t idx = rg.begin; idx < rg.end; idx += rg.stride) {
+    const Index4 ix = split_index(idx, dv, fast);  // (cg, tx, ty, b)
+    const int cg = ix.c0, tx = ix.c1, ty = ix.c2;
+    const int b = (int)ix.c3;
+    const int64_t t = ((int64_t)b * nTh + ty) * nTw + tx;
+    const int y0 = ty * M - 1, x0 = tx * M - 1;
+    const int64_t base = (int64_t)b * H * W * C + (int64_t)cg * VEC;
+    const float* xb = x + (int64_t)b * H * W * xps + (int64_t)cg * VEC;
+    float sc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) sc[e] = scale ? scale[cg * VEC + e] : 1.f;
+    float tmp[A][A][VEC];
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+      const int xx = x0 + j;
+      float col[A][VEC];
+#pragma unroll
+      for (int i = 0; i < A; ++i) {
+        const int yy = y0 + i;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+          vload<VEC>(xb + ((int64_t)yy * W + xx) * xps, col[i]);
+          if (gate) {
+            float gt[VEC];
+            vload<VEC>(gate + base + ((int64_t)yy * W + xx) * C, gt);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) col[i][e] = gt[e] > 0.f ? col[i][e] * sc[e] : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) col[i][e] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < A; ++i) {
+        bool first = true;
+#pragma unroll
+        for (int k = 0; k < A; ++k) axpy<VEC>(wino_bt(M, i, k), col[k], tmp[i][j], first);
+      }
+    }
+    float* vb = V + t * vts + (int64_t)cg * VEC;
+    uint32_t vmax = 0;
+#pragma unroll
+    for (int i = 0; i < A; ++i)
+#pragma unroll
+      for (int j = 0; j < A; ++j) {
+        float v[VEC];
+        bool first = true;
+#pragma unroll
+        for (int k = 0; k < A; ++k) axpy<VEC>(wino_bt(M, j, k), tmp[i][k], v, first);
+        vstore<VEC>(vb + (int64_t)(i * A + j) * T * vts, v);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const uint32_t b = __float_as_uint(v[e]) & 0x7fffffffu;
+          vmax = b > vmax ? b : vmax;
+        }
+      }
+    if (amax_out != nullptr) {   // kernel-uniform
+      const int ti = (int)t;
+      const bool whole = __ballot(1) == ~0ull && __all(ti == __shfl(ti, 0, 64));
+      if (whole) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const uint32_t other = (uint32_t)__shfl_xor((int)vmax, o, 64);
+          vmax = other > vmax ? other : vmax;
+        }
+        if ((threadIdx.x & 63) == 0) atomicMax(amax_out + t, vmax);
+      } else {
+        atomicMax(amax_out + t, vmax);
+      }
+    }
+  }
+}
+
 // ---- output transform: y tile = act(scale[c] * (A^T m A) + bias[c]), m[k] = M[k][t][c]; act = ReLU or identity ---
 template <int M, int VEC>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mx, const float* __restrict__ addend,
@@ -285,6 +371,12 @@ __global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restric
 
 using namespace sea;
 
+// A/B (env SEA_WINO_IN_VEC4, read per call): 1 = the F(4,3) input transform with four channels per lane
+static inline int wino_in_vec4() {
+  const char* e = getenv("SEA_WINO_IN_VEC4");
+  return e ? atoi(e) : 1;
+}
+
 static bool wino_dims(int B, int C, int H, int W, int m, int vec, int* nTh, int* nTw, int64_t* T) {
   if (!(B > 0 && C > 0 && H > 0 && W > 0 && (m == 2 || m == 4) && (C % vec) == 0)) return false;
   *nTh = (H + m - 1) / m;
@@ -329,6 +421,11 @@ static int wino_input_impl(const float* x, int64_t x_pixel_stride, const float* 
     hipLaunchKernelGGL((wino_input_kernel<2, 4>), dim3(grid_for_xcd(total, 256)), dim3(256), 0, (hipStream_t)stream, x, gate,
                        scale, V, C, H, W, nTh, nTw, T, total, x_pixel_stride, v_tile_stride, xcd_order_enabled() == 2, divs3(C / 4, nTw, nTh),
                        amax_out);
+  } else if (wino_in_vec4() & 1) {
+    const int64_t total = T * (C / 4);
+    hipLaunchKernelGGL((wino_input_cols_kernel<4, 4>), dim3(grid_for_xcd(total, 256)), dim3(256), 0, (hipStream_t)stream, x, gate,
+                       scale, V, C, H, W, nTh, nTw, T, total, x_pixel_stride, v_tile_stride, xcd_order_enabled() == 2, divs3(C / 4, nTw, nTh),
+                       amax_out);
   } else {
     const int64_t total = T * (C / 2);
     hipLaunchKernelGGL((wino_input_kernel<4, 2>), dim3(grid_for_xcd(total, 256)), dim3(256), 0, (hipStream_t)stream, x, gate,
@@ -347,6 +444,10 @@ extern "C" int sea_wino_output_transform(const float* Mx, const float* addend, c
   if (m == 2) {
     const int64_t total = T * (C / 4);
     hipLaunchKernelGGL((wino_output_kernel<2, 4>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, Mx,
+                       addend, scale, bias, relu, y, C, H, W, nTh, nTw, T, total, divs3(C / 4, nTw, nTh));
+  } else if (wino_in_vec4() & 2) {     // (A/B bit 2: four channels per lane in the output transform too)
+    const int64_t total = T * (C / 4);
+    hipLaunchKernelGGL((wino_output_kernel<4, 4>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, Mx,
                        addend, scale, bias, relu, y, C, H, W, nTh, nTw, T, total, divs3(C / 4, nTw, nTh));
   } else {
     const int64_t total = T * (C / 2);

@@ -12,6 +12,7 @@
 //              then df = dG @ W^T at the coarse resolution
 // Lanes run along channels (float4): every access is coalesced; the 9 taps share one pass over the footprint window.
 #include "sea_common.h"
+#include <utility>
 #include "bilinear_map.h"
 
 namespace sea {
@@ -22,11 +23,71 @@ namespace sea {
 // bound by L2 bandwidth at 16 TB/s of corner re-reads).
 constexpr int kTB = 4;
 
+// ---- interior blocks of a power-of-two factor: every weight is a compile-time constant ----------------------------------
+// For S = 4 / 8 the sample rows P = Y0 + q + a - 1 of a 4 x 4 block (Y0 a multiple of 4, phase Y0 mod S) map to
+// i0 = cy + (u >> log2 S) - 1, lambda = ((u & (S - 1)) + 0.5) / S with u = phase + q + a - 1 + S / 2 (axis_map_p2; cy = Y0 / S):
+// away from the borders nothing depends on the block but cy.  The general loop above evaluates 24 weights per tap and lane
+// (compares and selects around the float maps: as many VALU instructions as the interpolation itself) and multiplies by the
+// third of them that is zero; here the two live weights per sample are immediates and the dead products are not issued:
+// 208 -> us for the 16 x 16 -> 128 x 128 level (profiles/r6_tap_gather_ab.log).  Rounding differs from the general path in
+// the last bit (the tap's contribution goes into the accumulator term by term instead of as one sum).
+typedef float tg_f4 __attribute__((ext_vector_type(4)));
+
+template <int N, typename F, int... I>
+__device__ __forceinline__ void tg_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void tg_static_for(F&& f) {
+  tg_static_for_impl<N>(f, std::make_integer_sequence<int, N>{});
+}
+
+template <int S>
+struct TgAxis {   // one axis of one tap: u0 = phase + a - 1 + S / 2
+  static constexpr int LOG = S == 4 ? 2 : 3;
+  static constexpr int base(int u0) { return (u0 >> LOG) - 1; }                               // ib - c
+  static constexpr int k(int u0, int q) { return ((u0 + q) >> LOG) - (u0 >> LOG); }          // i0 - ib: 0 or 1
+  static constexpr float lam(int u0, int q) { return ((float)((u0 + q) & (S - 1)) + 0.5f) / (float)S; }
+};
+
+template <int S, int PHY, int PHX>
+__device__ __forceinline__ void tap_gather_inner(const float4* __restrict__ Gb, int cy, int cx, int w, int CG, tg_f4 (&acc)[kTB][kTB]) {
+  using AX = TgAxis<S>;
+  tg_static_for<9>([&](auto T) {
+    constexpr int tap = decltype(T)::value;
+    constexpr int a = tap / 3, bq = tap % 3;
+    constexpr int uy = PHY + a - 1 + S / 2, ux = PHX + bq - 1 + S / 2;
+    constexpr int NR = AX::k(uy, kTB - 1) + 2, NC = AX::k(ux, kTB - 1) + 2;                   // coarse rows / columns in use
+    const int ib = cy + AX::base(uy), jb = cx + AX::base(ux);
+    tg_f4 g[NR][NC];
+#pragma unroll
+    for (int k = 0; k < NR; ++k)
+#pragma unroll
+      for (int l = 0; l < NC; ++l) g[k][l] = *(const tg_f4*)(Gb + (uint32_t)((((ib + k) * w + jb + l) * 9 + tap) * CG));
+#pragma unroll
+    for (int py = 0; py < kTB; ++py) {
+      const int ky = AX::k(uy, py);
+      const float ly = AX::lam(uy, py);
+      tg_f4 t[NC];
+#pragma unroll
+      for (int l = 0; l < NC; ++l) t[l] = __builtin_elementwise_fma(tg_f4{ly, ly, ly, ly}, g[ky + 1][l], (1.f - ly) * g[ky][l]);
+#pragma unroll
+      for (int px = 0; px < kTB; ++px) {
+        const int kx = AX::k(ux, px);
+        const float lx = AX::lam(ux, px);
+        acc[py][px] = __builtin_elementwise_fma(tg_f4{1.f - lx, 1.f - lx, 1.f - lx, 1.f - lx}, t[kx], acc[py][px]);
+        acc[py][px] = __builtin_elementwise_fma(tg_f4{lx, lx, lx, lx}, t[kx + 1], acc[py][px]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);     // (one tap's loads at a time, as in the general loop)
+  });
+}
+
 template <int S>  // S = 4 / 8: that power-of-two factor in both axes (integer source map), 0: any factor >= 3
 __global__ __launch_bounds__(256) void tap_gather_fwd_kernel(const float4* __restrict__ G, float4* __restrict__ extra,
                                                              int accumulate, int CG, int h, int w, int H, int W, float rh,
                                                              float rw, int nBh, int nBw, int64_t total, int xcd,
-                                                             Divs3 dv) {
+                                                             Divs3 dv, int inner_ok) {
   const IndexRange rg = xcd_range(total, xcd);
   const bool fast = total < kFastIndexLimit;
   for (int64_t i = rg.begin; i < rg.end; i += rg.stride) {
@@ -43,6 +104,26 @@ __global__ __launch_bounds__(256) void tap_gather_fwd_kernel(const float4* __res
         acc[py][px] = (accumulate && Y0 + py < H && X0 + px < W) ? eb[(uint32_t)(((Y0 + py) * W + X0 + px) * CG)]
                                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4* Gb = G + (int64_t)b * h * w * 9 * CG + cg;
+    if constexpr (S == 4 || S == 8) {
+      if (inner_ok && Y0 - 1 >= S / 2 && Y0 + kTB + S / 2 < H && X0 - 1 >= S / 2 && X0 + kTB + S / 2 < W) {
+        tg_f4 (&va)[kTB][kTB] = reinterpret_cast<tg_f4 (&)[kTB][kTB]>(acc);
+        const int cy = Y0 / S, cx = X0 / S;
+        if constexpr (S == 4) {
+          tap_gather_inner<4, 0, 0>(Gb, cy, cx, w, CG, va);
+        } else {
+          const int ph = ((Y0 >> 2) & 1) * 2 + ((X0 >> 2) & 1);
+          if (ph == 0) tap_gather_inner<8, 0, 0>(Gb, cy, cx, w, CG, va);
+          else if (ph == 1) tap_gather_inner<8, 0, 4>(Gb, cy, cx, w, CG, va);
+          else if (ph == 2) tap_gather_inner<8, 4, 0>(Gb, cy, cx, w, CG, va);
+          else tap_gather_inner<8, 4, 4>(Gb, cy, cx, w, CG, va);
+        }
+#pragma unroll
+        for (int py = 0; py < kTB; ++py)
+#pragma unroll
+          for (int px = 0; px < kTB; ++px) eb[(uint32_t)(((Y0 + py) * W + X0 + px) * CG)] = acc[py][px];
+        continue;
+      }
+    }
 #pragma unroll 1  // one tap at a time: 9 loads in flight, ~150 VGPRs (fully unrolled the 81 loads spill)
     for (int tap = 0; tap < 9; ++tap) {
       const int a = tap / 3, bq = tap - a * 3;
@@ -278,10 +359,13 @@ extern "C" int sea_tap_gather_fwd(const float* G, float* extra, int accumulate, 
     const char* e = getenv("SEA_UPSAMPLE_GENERAL");
     return (e && e[0] == '1') ? 1 : 0;
   }();
+  // A/B (env SEA_TAP_INNER=0, read per call): the compile-time-weight path of interior blocks off
+  const char* tie = getenv("SEA_TAP_INNER");
+  const int inner_ok = (tie && tie[0] == '0') ? 0 : 1;
 #define SEA_LAUNCH_TAP_FWD(SS)                                                                                          \
   hipLaunchKernelGGL(tap_gather_fwd_kernel<SS>, dim3(grid_for_xcd(total, 256)), dim3(256), 0, (hipStream_t)stream,      \
                      (const float4*)G, (float4*)extra, accumulate, C / 4, h, w, H, W, (float)h / (float)H,              \
-                     (float)w / (float)W, nBh, nBw, total, xcd_order_enabled(), divs3(C / 4, nBw, nBh))
+                     (float)w / (float)W, nBh, nBw, total, xcd_order_enabled(), divs3(C / 4, nBw, nBh), inner_ok)
   if (!general_only && (int64_t)h * 4 == H && (int64_t)w * 4 == W) {
     SEA_LAUNCH_TAP_FWD(4);
   } else if (!general_only && (int64_t)h * 8 == H && (int64_t)w * 8 == W) {

@@ -23,16 +23,20 @@ namespace sea {
 
 // WM x WN waves (WM WN = 8), wave tile 64 x 32 TN; PRO: 0 none, 1 A * GELU'(t), 2 GELU(A), 3 t > 0 ? A : 0
 // DEPTH: register sets of staged loads (2 = a tile's loads are issued two K steps before its split)
-template <bool F16, int WM, int WN, int TN, int PRO, int DEPTH>
-__global__ __launch_bounds__(512, 2) void gemm_split_big_kernel(const GemmSplitArgs p) {
-  static_assert(WM * WN == 8, "eight waves");
+// MI: 32-row sub-tiles of a wave's tile (2: eight waves, two per SIMD; 4: FOUR waves of 128 x 128, one per SIMD, accumulators
+// in the AGPR half of the 512-register file -- a third fewer LDS fragment reads per MFMA)
+template <bool F16, int WM, int WN, int TN, int PRO, int DEPTH, int MI = 2>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_split_big_kernel(const GemmSplitArgs p) {
+  static_assert(WM * WN == 8 || (WM * WN == 4 && MI == 4), "eight waves, or four with 128-row wave tiles");
   constexpr int TERMS = 2;
-  constexpr int BM = 64 * WM, WT = 32 * TN, BN = WT * WN;
+  constexpr int NT = 64 * WM * WN;                         // threads
+  constexpr int RP = NT / 8;                               // rows of A staged per pass (eight float4 columns)
+  constexpr int BM = 32 * MI * WM, WT = 32 * TN, BN = WT * WN;
   constexpr int IMG_A = BM * 64, IMG_W = BN * 64;          // bytes of one term image (rows x 64 B)
   constexpr int STAGE = TERMS * (IMG_A + IMG_W);           // A images, then W images: 64 KB in both configurations
-  constexpr int NA = BM / 64;                              // float4 loads of A per thread and K step (rows arow + 64 i)
-  constexpr int NWT = BN / 128, NW = TERMS * NWT;          // 16-byte weight pieces per thread: per term, in all
-  constexpr int SLOTS = 6 * TN;                            // MFMAs of one 16-deep half: 2 TN chains of three products
+  constexpr int NA = BM / RP;                              // float4 loads of A per thread and K step (rows arow + RP i)
+  constexpr int NWT = BN * 4 / NT, NW = TERMS * NWT;       // 16-byte weight pieces per thread: per term, in all
+  constexpr int SLOTS = 3 * MI * TN;                       // MFMAs of one 16-deep half: MI TN chains of three products
   constexpr int UNIT_EVERY = SLOTS / (3 * NA);             // an A micro-unit behind every UNIT_EVERY-th product of the first half
   constexpr bool HAS_T = (PRO == 1 || PRO == 3);
   static_assert(STAGE == 65536 && SLOTS % (3 * NA) == 0 && NW + 2 <= SLOTS, "configuration");
@@ -54,7 +58,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_big_kernel(const GemmSplitA
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
-  const int q = tid & 7, arow = tid >> 3;              // A staging: float4 column q of rows arow + 64 i
+  const int q = tid & 7, arow = tid >> 3;              // A staging: float4 column q of rows arow + RP i
 
   const char* const Abase = (const char*)(p.A + (int64_t)g * p.strideA);
   const char* const Tbase = HAS_T ? (const char*)(p.a_gelu_grad_of + (int64_t)g * p.strideA) : nullptr;
@@ -69,16 +73,16 @@ __global__ __launch_bounds__(512, 2) void gemm_split_big_kernel(const GemmSplitA
   float a_sc[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) a_sc[i] = 1.f;
-  // One VGPR per address family (the K loop has no register to spare): rows arow + 64 i of A share their swizzle (64 rows
-  // further = the same (row >> 2) & 3), so their LDS offsets differ by 4096 i and their global offsets by a SCALAR 64 i lda
+  // One VGPR per address family (the K loop has no register to spare): rows arow + RP i of A share their swizzle (RP = 64 / 32
+  // rows further = the same (row >> 2) & 3), so their LDS offsets differ by 64 RP i and their global offsets by a SCALAR RP i lda
   // (a row past M takes the descriptor's size as its lane offset: out of range whatever the hardware adds to it -> zeros);
   // the weight pieces of a thread (tid + 512 j of a term's image: 128 rows further each) share theirs too.
   const uint32_t aoff0 = (uint32_t)(((int64_t)(m0 + arow) * lda + 4 * q) * 4);
   const uint32_t a_wr0 = (uint32_t)(arow * 64 + swz<false>(arow, q >> 1) + (q & 1) * 8);
   const int wrow0 = tid >> 2;
   const uint32_t w_wr0 = (uint32_t)(TERMS * IMG_A + wrow0 * 64 + swz<false>(wrow0, tid & 3));
-  const int a_row_step = (int)(64 * lda * 4);          // bytes between rows arow + 64 i (lda < 2^22: checked by the launcher)
-  const int ra = wm * 64 + r, rb = wn * WT + r;
+  const int a_row_step = (int)(RP * lda * 4);          // bytes between rows arow + RP i (lda < 2^22: checked by the launcher)
+  const int ra = wm * 32 * MI + r, rb = wn * WT + r;
   const uint32_t a_rd = (uint32_t)(ra * 64 + swz<false>(ra, h));                 // mi: + 2048, s: ^ 32, term: + IMG_A
   const uint32_t b_rd = (uint32_t)(TERMS * IMG_A + rb * 64 + swz<false>(rb, h));   // ni: + 2048, term: + IMG_W
 
@@ -96,25 +100,25 @@ __global__ __launch_bounds__(512, 2) void gemm_split_big_kernel(const GemmSplitA
 #pragma unroll
     for (int i = 0; i < NA; ++i)
       Ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-          rs, (int)((m0 + arow + 64 * i < M) ? aoff0 : a_bytes), kb * (GS_BK * 4) + i * a_row_step, 0));   // (rows past M: out of range -> zeros)
+          rs, (int)((m0 + arow + RP * i < M) ? aoff0 : a_bytes), kb * (GS_BK * 4) + i * a_row_step, 0));   // (rows past M: out of range -> zeros)
     if constexpr (HAS_T) {
       const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void*)Tbase, 0, live, 0x00020000);
 #pragma unroll
       for (int i = 0; i < NA; ++i)
         Rt[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-            rt, (int)((m0 + arow + 64 * i < M) ? aoff0 : a_bytes), kb * (GS_BK * 4) + i * a_row_step, 0));
+            rt, (int)((m0 + arow + RP * i < M) ? aoff0 : a_bytes), kb * (GS_BK * 4) + i * a_row_step, 0));
     }
   };
   auto fetch_w = [&](Tile& R, int kb) __attribute__((always_inline)) {
     u32x4 (&Rw)[NW] = R.w;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)Wbase, 0, kb < nkb ? (int)w_bytes : 0, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < NW; ++i)   // piece j = i % NWT of term i / NWT: bytes 8192 j + 16 tid of the term's image
+    for (int i = 0; i < NW; ++i)   // piece j = i % NWT of term i / NWT: bytes 16 NT j + 16 tid of the term's image
       Rw[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                            rs, (int)woff, kb * (int)w_kb + (i / NWT) * (int)w_term + (i % NWT) * 8192, 0));
+                                            rs, (int)woff, kb * (int)w_kb + (i / NWT) * (int)w_term + (i % NWT) * (16 * NT), 0));
   };
   auto write_w = [&](Tile& R, int i, char* stage) __attribute__((always_inline)) {
-    *(u32x4*)(stage + w_wr0 + (i / NWT) * IMG_W + (i % NWT) * 8192) = R.w[i];
+    *(u32x4*)(stage + w_wr0 + (i / NWT) * IMG_W + (i % NWT) * (16 * NT)) = R.w[i];
   };
 
   // staging micro-units of A row i (see gemm_split_pp.hip): (0) prologue + scale + first term, (1) remainder, (2) second term + writes
@@ -162,17 +166,17 @@ __global__ __launch_bounds__(512, 2) void gemm_split_big_kernel(const GemmSplitA
         sv[3] -= __uint_as_float(hi_b & 0xffff0000u);
       }
     } else {
-      *(u32x2*)(stage + a_wr0 + 4096 * i) = u32x2{hi_a, hi_b};
+      *(u32x2*)(stage + a_wr0 + 64 * RP * i) = u32x2{hi_a, hi_b};
       const u32x2 mid = F16 ? u32x2{pack_f16(sv[0], sv[1]), pack_f16(sv[2], sv[3])}
                             : u32x2{pack_bf16(sv[0], sv[1]), pack_bf16(sv[2], sv[3])};
-      *(u32x2*)(stage + IMG_A + a_wr0 + 4096 * i) = mid;
+      *(u32x2*)(stage + IMG_A + a_wr0 + 64 * RP * i) = mid;
     }
   };
 
-  bf16x8 fa[2][TERMS], fb[TN][TERMS];
+  bf16x8 fa[MI][TERMS], fb[TN][TERMS];
   auto read_a = [&](const char* stage, int s) __attribute__((always_inline)) {
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int t = 0; t < TERMS; ++t) fa[mi][t] = *(const bf16x8*)(stage + ((a_rd ^ (uint32_t)(32 * s)) + mi * 2048 + t * IMG_A));
   };
@@ -189,9 +193,9 @@ __global__ __launch_bounds__(512, 2) void gemm_split_big_kernel(const GemmSplitA
       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][ia], fb[ni][ib], c, 0, 0, 0);
   };
 
-  f32x16 acc[2][TN];
+  f32x16 acc[MI][TN];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
@@ -206,11 +210,11 @@ __global__ __launch_bounds__(512, 2) void gemm_split_big_kernel(const GemmSplitA
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
+      for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
           mfma3(acc[mi][ni], mi, ni, j);
-          const int slot = (ni * 2 + mi) * 3 + j;
+          const int slot = (ni * MI + mi) * 3 + j;
           if (slot % UNIT_EVERY == 0 && unit < 3 * NA) {
             unit_a(Rn, unit / 3, unit % 3, nxt);
             ++unit;
@@ -226,11 +230,11 @@ __global__ __launch_bounds__(512, 2) void gemm_split_big_kernel(const GemmSplitA
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
+      for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
           mfma3(acc[mi][ni], mi, ni, j);
-          const int slot = (ni * 2 + mi) * 3 + j;
+          const int slot = (ni * MI + mi) * 3 + j;
           if (slot < NW) write_w(Rn, slot < NW ? slot : 0, nxt);
           if (slot == NW) fetch_a(Rn, kf);
           if (slot == NW + 1) fetch_w(Rn, kf);
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_big_kernel(const GemmSplitA
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < NA; ++i) a_sc[i] = row_sc[arow + 64 * i];
+    for (int i = 0; i < NA; ++i) a_sc[i] = row_sc[arow + RP * i];
   }
   SEA_PIN();
 #pragma unroll
@@ -307,7 +311,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_big_kernel(const GemmSplitA
     wi_c[ni] = (F16 && col < N) ? w_inv[col] : 1.f;
   }
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const int row0_u = m0 + (wave_u / WN) * 64;
+  const int row0_u = m0 + (wave_u / WN) * 32 * MI;
   float* const Cg = p.C + (int64_t)g * p.strideC;
   constexpr int SCR = 32 * WT * 4;                      // bytes of a wave's 32-row scratch: 16 KB / 12 KB
   char* const scr = smem + wave_u * SCR;
@@ -316,14 +320,14 @@ __global__ __launch_bounds__(512, 2) void gemm_split_big_kernel(const GemmSplitA
   const int relu = p.relu;
   uint32_t omax = 0;
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
+  for (int mi = 0; mi < MI; ++mi) {
     if (mi) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row_l = (e & 3) + 8 * (e >> 2) + 4 * h;
-        const float v = (F16 ? acc[mi][ni][e] * (row_inv[(wave_u / WN) * 64 + mi * 32 + row_l] * wi_c[ni]) : acc[mi][ni][e]) + bv_c[ni];
+        const float v = (F16 ? acc[mi][ni][e] * (row_inv[(wave_u / WN) * 32 * MI + mi * 32 + row_l] * wi_c[ni]) : acc[mi][ni][e]) + bv_c[ni];
         *(float*)(scr + (row_l * WT + ni * 32 + r) * 4) = v;
       }
     }
@@ -364,10 +368,10 @@ __global__ __launch_bounds__(512, 2) void gemm_split_big_kernel(const GemmSplitA
   }
 }
 
-template <bool F16, int WM, int WN, int TN, int PRO, int DEPTH>
+template <bool F16, int WM, int WN, int TN, int PRO, int DEPTH, int MI = 2>
 static void big_launch_one(const GemmSplitArgs& p, hipStream_t st) {
-  constexpr int lds = 2 * 65536 + 2 * 64 * WM * (int)sizeof(float);
-  auto k = gemm_split_big_kernel<F16, WM, WN, TN, PRO, DEPTH>;
+  constexpr int lds = 2 * 65536 + 2 * 32 * MI * WM * (int)sizeof(float);
+  auto k = gemm_split_big_kernel<F16, WM, WN, TN, PRO, DEPTH, MI>;
   static bool attr_set_dev[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -375,7 +379,7 @@ static void big_launch_one(const GemmSplitArgs& p, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set_dev[dev & 63] = true;
   }
-  hipLaunchKernelGGL(k, dim3(p.per_xcd * 8), dim3(512), (size_t)lds, st, p);
+  hipLaunchKernelGGL(k, dim3(p.per_xcd * 8), dim3(64 * WM * WN), (size_t)lds, st, p);
 }
 
 // launches a one-block-per-CU kernel; the caller has checked: terms 22 or 2, no fused epilogue extras.
@@ -393,6 +397,12 @@ bool gemm_split_big_launch(GemmSplitArgs p, int terms, int batch, int shape, int
   p.per_xcd = (p.total + 7) / 8;
   const bool f16 = terms == 22;
   if (shape == 0) {
+    // A/B (env SEA_GEMM_BIG_WAVES, read per call): 4 = four waves of 128 x 128
+    const char* e = getenv("SEA_GEMM_BIG_WAVES");
+    if (f16 && e && e[0] == '4') {
+      big_launch_one<true, 2, 2, 4, 0, 1, 4>(p, st);
+      return true;
+    }
     if (f16) big_launch_one<true, 4, 2, 4, 0, 1>(p, st); else big_launch_one<false, 4, 2, 4, 0, 1>(p, st);
     return true;
   }

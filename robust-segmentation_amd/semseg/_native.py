@@ -682,8 +682,11 @@ def wino_filter(weight, m: int, flip: bool):
     return U
 
 
-# fewest Winograd tiles (rows of each of the 36 / 16 Winograd-domain products) that go through M8; below: hipBLASLt's batched fp32 GEMM
-WINO_SPLIT_MIN_TILES = int(os.environ.get("SEA_WINO_SPLIT_MIN_TILES", "128"))
+# fewest Winograd tiles PER IMAGE (rows of each of the 36 / 16 Winograd-domain products, divided by the batch) that go through
+# M8; below: hipBLASLt's batched fp32 GEMM.  Per image, not in total: which arithmetic an image gets must not depend on how
+# many partners its batch has (a sharded evaluation equals the unsharded one bit for bit).  16 = a 16 x 16 map at F(4,3):
+# the PSP bottleneck (2816 -> 512) of a 512 x 512 input, 145 + 164 us on the library against ~85 + ~85 us here.
+WINO_SPLIT_MIN_TILES = int(os.environ.get("SEA_WINO_SPLIT_MIN_TILES", "16"))
 
 
 def wino_conv3x3_cl(x, U, m: int, bias=None, scale=None, relu: bool = False, gate=None, gate_scale=None,
@@ -711,7 +714,7 @@ def wino_conv3x3_cl(x, U, m: int, bias=None, scale=None, relu: bool = False, gat
     T = L.sea_wino_tiles(B, H, W, m)
     V = torch.empty(A2, T, Cin, dtype=torch.float32, device=xs[0].device)
     off = 0
-    use_split = gemm_terms in (1, 2, 3, 22) and Cin % 32 == 0 and T >= WINO_SPLIT_MIN_TILES
+    use_split = gemm_terms in (1, 2, 3, 22) and Cin % 32 == 0 and T // B >= WINO_SPLIT_MIN_TILES
     # fp16 x 2: one scale word per tile (= per row of the Winograd-domain GEMMs), filled by the transform itself
     v_amax = (torch.zeros(T, dtype=torch.int32, device=xs[0].device)
               if (use_split and gemm_terms == 22 and AMAX_FROM_PRODUCERS) else None)

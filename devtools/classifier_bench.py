@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""M9 (classifier kernels, csrc/classifier.hip) against the library matmul on the headline shape (8 x 128 x 128 pixels,
+"""M10 (classifier kernels, csrc/classifier.hip) against the library matmul on the headline shape (8 x 128 x 128 pixels,
 512 -> 21): hot (one buffer) and cold (a ring larger than the Infinity Cache).
 
     python devtools/classifier_bench.py
@@ -44,7 +44,7 @@ def main():
             hot_f, hot_b = timed(lambda: f(ys[0]), 10), timed(lambda: gfn(gs[0]), 10)
             cold_f = timed(lambda: [f(y) for y in ys], 1) / 4
             cold_b = timed(lambda: [gfn(g) for g in gs], 1) / 4
-            print(f"M9 classifier cls={cls:3d} {name:8s} fwd hot {hot_f * 1e3:6.1f} us cold {cold_f * 1e3:6.1f} us ({mb / cold_f / 1e3:5.2f} TB/s)"
+            print(f"M10 classifier cls={cls:3d} {name:8s} fwd hot {hot_f * 1e3:6.1f} us cold {cold_f * 1e3:6.1f} us ({mb / cold_f / 1e3:5.2f} TB/s)"
                   f"   bwd hot {hot_b * 1e3:6.1f} us cold {cold_b * 1e3:6.1f} us ({mb / cold_b / 1e3:5.2f} TB/s)", flush=True)
 
 

@@ -492,7 +492,7 @@ int sea_gemm_split(const float* A, int64_t lda, const void* Wp, float* C, int64_
                    int N, int K, int terms, int batch, int64_t strideA, int64_t strideW_bytes, int64_t strideC,
                    void* stream);
 /* ------------------------------------------------------------------------------------------------
- * M9   the decode head's classifier, a 1 x 1 convolution onto a SMALL number of classes (semseg/models/uperforseg.py:262
+ * M10  the decode head's classifier, a 1 x 1 convolution onto a SMALL number of classes (semseg/models/uperforseg.py:262
  *      `cls_seg`; reference autograd for the input gradient), forward and input gradient for frozen weights, on
  *      v_mfma_f32_32x32x2_f32 (exact fp32 products).  Replaces torch.matmul (hipBLASLt) on these shapes.
  *   y / gy: (B P, K) fp32 NHWC rows, contiguous, 16-byte aligned; W: (cls, K) contiguous, 16-byte aligned; bias (cls) or NULL;

@@ -1,4 +1,4 @@
-// M9: the decode head's final 1 x 1 convolution (reference semseg/models/uperforseg.py:262, `cls_seg` -> conv_seg) for a
+// M10: the decode head's final 1 x 1 convolution (reference semseg/models/uperforseg.py:262, `cls_seg` -> conv_seg) for a
 // SMALL number of classes (<= 32: PASCAL-VOC's 21), forward and input gradient, frozen weights.
 //
 //   forward   logits[b][c][p] = sum_k W[c][k] y[b][p][k] + bias[c]     y: NHWC rows (B P, K), logits: NCHW (B, cls, P)

@@ -970,7 +970,7 @@ USE_CLASSIFIER = os.environ.get("SEA_CLASSIFIER", "1") != "0"
 
 
 def classifier_ok(P: int, K: int, cls: int) -> bool:
-    """the head's 1 x 1 classifier has its own kernels for this shape (M9: at most 32 classes)"""
+    """the head's 1 x 1 classifier has its own kernels for this shape (M10: at most 32 classes)"""
     return bool(USE_CLASSIFIER and lib().sea_classifier_supported(int(P), int(K), int(cls)))
 
 

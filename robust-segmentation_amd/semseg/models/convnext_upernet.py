@@ -1277,7 +1277,7 @@ class _FpnBottleneck(torch.autograd.Function):
 
 class _FpnBottleneckClassify(torch.autograd.Function):
     """_FpnBottleneck followed by the head's classifier (uperforseg.py:296-304 + 262) as ONE autograd node, for at most 32
-    classes (M9): the classifier's input-gradient kernel applies the bottleneck's ReLU gate and BatchNorm scale on the way
+    classes (M10): the classifier's input-gradient kernel applies the bottleneck's ReLU gate and BatchNorm scale on the way
     out, so the 0.8 GB gate pass between the two backward steps disappears; same bits as the two nodes."""
 
     @staticmethod
@@ -1375,7 +1375,7 @@ class _ClassifierGemm(torch.autograd.Function):
         B, Cin, H, W = y.shape
         ctx.w2d, ctx.shape = w2d, (B, Cin, H, W)
         ctx.own = N.classifier_ok(H * W, Cin, w2d.shape[0]) and w2d.is_contiguous() and (bias is None or bias.is_contiguous())
-        if ctx.own:     # M9: at most 32 classes on the fp32 matrix cores, y read once (csrc/classifier.hip)
+        if ctx.own:     # M10: at most 32 classes on the fp32 matrix cores, y read once (csrc/classifier.hip)
             rows = y.permute(0, 2, 3, 1).reshape(B * H * W, Cin)
             return N.classifier_forward(rows, w2d, bias, B, H * W).view(B, w2d.shape[0], H, W)
         out = torch.matmul(w2d, y.permute(0, 2, 3, 1).reshape(B, H * W, Cin).transpose(1, 2))
@@ -1399,7 +1399,7 @@ FUSE_CLASSIFIER_GATE = os.environ.get("SEA_FUSE_CLS_GATE", "1") != "0"   # A/B: 
 
 
 def _classifier_fusable(conv: nn.Conv2d, cin, f0):
-    """the classifier behind the fused FPN bottleneck can ride in its autograd node (M9 kernels, frozen fp32 weights)"""
+    """the classifier behind the fused FPN bottleneck can ride in its autograd node (M10 kernels, frozen fp32 weights)"""
     from .. import _native as N
     return (FUSE_CLASSIFIER_GATE and conv.kernel_size == (1, 1) and conv.in_channels == cin and not torch.is_autocast_enabled()
             and conv.weight.dtype == torch.float32 and not conv.weight.requires_grad

@@ -1,4 +1,4 @@
-"""M9: the decode head's 1 x 1 classifier for at most 32 classes (csrc/classifier.hip), `-m gpu`.
+"""M10: the decode head's 1 x 1 classifier for at most 32 classes (csrc/classifier.hip), `-m gpu`.
 
 Reference layer: semseg/models/uperforseg.py:262 (`cls_seg`: conv_seg, a 1 x 1 convolution onto the classes) and its autograd
 input gradient.  The kernels use f32 MFMA operands (exact products), so the yardstick is float64: the error must not exceed

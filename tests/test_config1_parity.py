@@ -57,11 +57,12 @@ def test_config1_device_path_matches_reference(tile):
     g, model, x, y, w, noises = _setup()
     model = model.cuda()
     old_tile, M.WINOGRAD_TILE = M.WINOGRAD_TILE, tile
+    shipped = A.FUSE_UPSAMPLE
     try:
         _run_config1(A, g, model, x, y, w, noises)
     finally:
         M.WINOGRAD_TILE = old_tile
-        A.FUSE_UPSAMPLE = False
+        A.FUSE_UPSAMPLE = shipped
     assert all(p.requires_grad for p in model.parameters())  # the attack restores the flags it froze
 
 

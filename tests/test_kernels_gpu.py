@@ -385,11 +385,14 @@ def test_fused_and_unfused_attack_agree(N):
     with torch.no_grad():
         y = net(x).max(1)[1]
     outs = []
-    for fuse in (True, False):
-        A.FUSE_UPSAMPLE = fuse
-        outs.append(A.apgd_train(net, x, y, "Linf", 8 / 255, n_iter=8, loss="mask-ce-avg", track_loss="ce-avg",
-                                 num_classes=7))
-    A.FUSE_UPSAMPLE = False
+    shipped = A.FUSE_UPSAMPLE          # ("auto" since round 6: restored below -- a leaked False changes every later in-process run)
+    try:
+        for fuse in (True, False):
+            A.FUSE_UPSAMPLE = fuse
+            outs.append(A.apgd_train(net, x, y, "Linf", 8 / 255, n_iter=8, loss="mask-ce-avg", track_loss="ce-avg",
+                                     num_classes=7))
+    finally:
+        A.FUSE_UPSAMPLE = shipped
     (xb, acc, lb, xba), (xb2, acc2, lb2, xba2) = outs
     assert (acc - acc2).abs().max() <= 3.0 / 4096
     torch.testing.assert_close(lb, lb2, rtol=1e-3, atol=1e-4)

@@ -15,9 +15,9 @@ timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $RAW/fetch -- pyth
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $RAW/write -- python3 $CASES > $RAW/write.log 2>&1
 SEA_PROFILE_REPS=2 timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES \
   --output-format csv -d $RAW/sq -- python3 $CASES > $RAW/sq.log 2>&1 || tail -3 $RAW/sq.log
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/bench -- python3 bench.py --steps 10 --warmup 2 --sustain 0 --no-cpu-baseline --no-model-roofline > $RAW/prof_bench.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/bench_s -- python3 bench.py --steps 10 --warmup 2 --sustain 0 --no-cpu-baseline --no-model-roofline --backbone ConvNeXt-S_CVST --classes 151 > $RAW/prof_bench_cnxs.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/bench_v -- python3 bench.py --steps 10 --warmup 2 --sustain 0 --no-cpu-baseline --no-model-roofline --backbone vit_small_patch16_224 --classes 151 > $RAW/prof_bench_vits.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/bench -- python3 bench.py --steps 10 --warmup 2 --sustain 0 --no-cpu-baseline --no-model-roofline --strict-steps 0 > $RAW/prof_bench.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/bench_s -- python3 bench.py --steps 10 --warmup 2 --sustain 0 --no-cpu-baseline --no-model-roofline --strict-steps 0 --backbone ConvNeXt-S_CVST --classes 151 > $RAW/prof_bench_cnxs.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/bench_v -- python3 bench.py --steps 10 --warmup 2 --sustain 0 --no-cpu-baseline --no-model-roofline --strict-steps 0 --backbone vit_small_patch16_224 --classes 151 > $RAW/prof_bench_vits.log 2>&1
 python3 robust-segmentation_amd/tools/summarize_profile.py --round ${R}_cnxs_c151 --bench $RAW/bench_s --title "B=8, C=151, 512x512, UperNet-ConvNeXt-S, fp32" | tail -2
 python3 robust-segmentation_amd/tools/summarize_profile.py --round ${R}_vits_c151 --bench $RAW/bench_v --title "B=8, C=151, 512x512, Segmenter ViT-S/16, fp32" | tail -2
 SQ=""

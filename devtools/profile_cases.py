@@ -70,8 +70,14 @@ for gi, (C, hl, lab) in enumerate(((21, 128, "x4"), (151, 128, "x4"), (151, 32, 
         for r in range(REPS):
             N.loss_fwd_bwd_upsampled(low, y8, w, 1, 3, 1.0 / HW, grad, pred=pred, dlow=dlow if grad else None)
         torch.cuda.synchronize()
-    case(f"K2u C={C} {lab} +grad", "loss_upsampled_kernel<true>", B * HW * (2 * C * 4 + 16), B * (2 * C * hl * hl * 4 + 2 * HW), gi, 3)
-    case(f"K2u C={C} {lab} no-grad", "loss_upsampled_kernel<false>", B * HW * (C * 4 + 16), B * (C * hl * hl * 4 + 2 * HW), gi, 3)
+    # round 6: the power-of-two kernel loss_upsampled_pow2_kernel<S, lane slots of the class vector, GRAD> (+ a small combine
+    # kernel for the cells' top / bottom partial rows, priced with the gather it completes: listed on its own line)
+    S, NS = H // hl, -(-C // 64)
+    # (below 96 classes the general gather kernel runs: the only C = 21 case)
+    kt, kf = ((f"loss_upsampled_pow2_kernel<{S}, {NS}, true>", f"loss_upsampled_pow2_kernel<{S}, {NS}, false>") if C >= 96 else
+              ("loss_upsampled_kernel<true>", "loss_upsampled_kernel<false>"))
+    case(f"K2u C={C} {lab} +grad", kt, B * HW * (2 * C * 4 + 16), B * (2 * C * hl * hl * 4 + 2 * HW))
+    case(f"K2u C={C} {lab} no-grad", kf, B * HW * (C * 4 + 16), B * (C * hl * hl * 4 + 2 * HW))
 
 # ---- K1 / K5 / K6 / K4 (25 MB tensors: ring of 16 sets = 2 GB) ----------------------------------------------------------------
 g = torch.Generator(device="cuda").manual_seed(1)

@@ -41,6 +41,12 @@ def sea_key(n):
     m = re.search(r"loss_nchw_fwd<(\w+), (\d+), (\d+)>", n)
     if m:
         return f"K2 loss_nchw_fwd<{m.group(1)},chunk={m.group(2)},waves={m.group(3)}>"
+    m = re.search(r"loss_upsampled_pow2_kernel<(\d+), (\d+), (\w+)>", n)
+    if m:
+        return f"K2u loss_upsampled_pow2<x{m.group(1)},slots={m.group(2)},grad={m.group(3)}>"
+    m = re.search(r"loss_upsampled_pow2_combine<(\d+)>", n)
+    if m:
+        return f"K2u loss_upsampled_pow2_combine<x{m.group(1)}>"
     for pat, key in (("loss_nhwc_lds", "K2 loss_nhwc_lds"), ("loss_upsampled_kernel", "K2u loss_upsampled_kernel"),
                      ("stream_copy_kernel", "probe stream_copy"), ("stream_read_kernel", "probe stream_read"), ("loss_nchw_stream", "K2 loss_nchw_stream"),
                      ("loss_finalize", "K2 loss_finalize"), ("apgd_linf_step", "K1 apgd_linf_step"),

@@ -73,9 +73,8 @@ for gi, (C, hl, lab) in enumerate(((21, 128, "x4"), (151, 128, "x4"), (151, 32, 
     # round 6: the power-of-two kernel loss_upsampled_pow2_kernel<S, lane slots of the class vector, GRAD> (+ a small combine
     # kernel for the cells' top / bottom partial rows, priced with the gather it completes: listed on its own line)
     S, NS = H // hl, -(-C // 64)
-    # (below 96 classes the general gather kernel runs: the only C = 21 case)
-    kt, kf = ((f"loss_upsampled_pow2_kernel<{S}, {NS}, true>", f"loss_upsampled_pow2_kernel<{S}, {NS}, false>") if C >= 96 else
-              ("loss_upsampled_kernel<true>", "loss_upsampled_kernel<false>"))
+    # (called through the C ABI every class count takes the power-of-two kernel; the ATTACKER fuses only from 96 classes on)
+    kt, kf = f"loss_upsampled_pow2_kernel<{S}, {NS}, true>", f"loss_upsampled_pow2_kernel<{S}, {NS}, false>"
     case(f"K2u C={C} {lab} +grad", kt, B * HW * (2 * C * 4 + 16), B * (2 * C * hl * hl * 4 + 2 * HW))
     case(f"K2u C={C} {lab} no-grad", kf, B * HW * (C * 4 + 16), B * (C * hl * hl * 4 + 2 * HW))
 

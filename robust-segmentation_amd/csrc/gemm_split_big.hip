@@ -25,7 +25,10 @@ namespace sea {
 // DEPTH: register sets of staged loads (2 = a tile's loads are issued two K steps before its split)
 // MI: 32-row sub-tiles of a wave's tile (2: eight waves, two per SIMD; 4: FOUR waves of 128 x 128, one per SIMD, accumulators
 // in the AGPR half of the 512-register file -- a third fewer LDS fragment reads per MFMA)
-template <bool F16, int WM, int WN, int TN, int PRO, int DEPTH, int MI = 2>
+// WDMA: the packed weights go straight into the LDS stage by LDS-DMA (global_load_lds_dwordx4: the chunk swizzle applied to the
+// SOURCE address, one wave-instruction = 16 rows of an image = 1 KB of LDS in lane order): no staging registers, no ds_write for
+// half of a K step's LDS bytes
+template <bool F16, int WM, int WN, int TN, int PRO, int DEPTH, int MI = 2, bool WDMA = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_split_big_kernel(const GemmSplitArgs p) {
   static_assert(WM * WN == 8 || (WM * WN == 4 && MI == 4), "eight waves, or four with 128-row wave tiles");
   constexpr int TERMS = 2;
@@ -40,6 +43,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_big_kernel(const Gemm
   constexpr int UNIT_EVERY = SLOTS / (3 * NA);             // an A micro-unit behind every UNIT_EVERY-th product of the first half
   constexpr bool HAS_T = (PRO == 1 || PRO == 3);
   static_assert(STAGE == 65536 && SLOTS % (3 * NA) == 0 && NW + 2 <= SLOTS, "configuration");
+  constexpr int NBLK = TERMS * BN / 16;                    // WDMA: 1 KB blocks (16 rows of an image) of a stage's weights
+  constexpr int NVM = NA * (HAS_T ? 2 : 1);                // vector-memory loads a step issues AFTER its DMAs (fetch_a)
+  static_assert(!WDMA || (NT == 512 && NBLK % 8 == 0 && DEPTH == 1), "LDS-DMA weights: eight waves, one register set");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* const row_sc = (float*)(smem + 2 * STAGE);
   float* const row_inv = row_sc + BM;
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_big_kernel(const Gemm
   struct Tile {
     f32x4 a[NA];
     f32x4 t[HAS_T ? NA : 1];
-    u32x4 w[NW];
+    u32x4 w[WDMA ? 1 : NW];
   };
   Tile R0 = {}, R1 = {};
   auto fetch_a = [&](Tile& R, int kb) __attribute__((always_inline)) {
@@ -109,8 +115,24 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_big_kernel(const Gemm
             rt, (int)((m0 + arow + RP * i < M) ? aoff0 : a_bytes), kb * (GS_BK * 4) + i * a_row_step, 0));
     }
   };
+  const int wave_u0 = __builtin_amdgcn_readfirstlane(wave);
+  const uint32_t lane_off = (uint32_t)((lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) * 16));
+  auto dma_w = [&](char* stage, int kb) __attribute__((always_inline)) {
+    if constexpr (WDMA) {
+      const int kbc = kb < nkb ? kb : nkb - 1;               // (past the end of K: a valid block again, never consumed)
+#pragma unroll
+      for (int i = 0; i < NBLK / 8; ++i) {
+        const int blk = wave_u0 + 8 * i;                     // wave-uniform: block of 16 rows
+        const int t = blk / (BN / 16), rb16 = blk - t * (BN / 16);
+        const char* const src = Wbase + (int64_t)kbc * w_kb + (int64_t)t * w_term + rb16 * 1024 + lane_off;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(stage + TERMS * IMG_A + blk * 1024), 16, 0, 0);
+      }
+    }
+  };
   auto fetch_w = [&](Tile& R, int kb) __attribute__((always_inline)) {
-    u32x4 (&Rw)[NW] = R.w;
+    if constexpr (WDMA) return;
+    u32x4 (&Rw)[WDMA ? 1 : NW] = R.w;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)Wbase, 0, kb < nkb ? (int)w_bytes : 0, 0x00020000);
 #pragma unroll
     for (int i = 0; i < NW; ++i)   // piece j = i % NWT of term i / NWT: bytes 16 NT j + 16 tid of the term's image
@@ -118,7 +140,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_big_kernel(const Gemm
                                             rs, (int)woff, kb * (int)w_kb + (i / NWT) * (int)w_term + (i % NWT) * (16 * NT), 0));
   };
   auto write_w = [&](Tile& R, int i, char* stage) __attribute__((always_inline)) {
-    *(u32x4*)(stage + w_wr0 + (i / NWT) * IMG_W + (i % NWT) * (16 * NT)) = R.w[i];
+    if constexpr (!WDMA) *(u32x4*)(stage + w_wr0 + (i / NWT) * IMG_W + (i % NWT) * (16 * NT)) = R.w[i];
   };
 
   // staging micro-units of A row i (see gemm_split_pp.hip): (0) prologue + scale + first term, (1) remainder, (2) second term + writes
@@ -207,6 +229,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_big_kernel(const Gemm
   // by column as it releases their registers; the second half carries the weight pieces and the refill loads.
   auto step = [&](char* cur, char* nxt, Tile& Rn, int kf) __attribute__((always_inline)) {
     int unit = 0;
+    dma_w(nxt, kf - DEPTH);                                          // (nobody reads `nxt` since the last barrier)
+    SEA_PIN();
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
 #pragma unroll
@@ -242,6 +266,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_big_kernel(const Gemm
         }
       }
     }
+    if constexpr (WDMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NVM) : "memory");   // the DMAs are older than this step's fetch_a loads
     __syncthreads();                                               // every wave is done with `cur` and has written `nxt`
     read_a(nxt, 0);
 #pragma unroll
@@ -254,6 +279,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_big_kernel(const Gemm
   // ---- prologue
   Tile& RA = R0;
   Tile& RB = DEPTH == 2 ? R1 : R0;
+  dma_w(smem, 0);
   fetch_a(R0, 0);
   fetch_w(R0, 0);
   if constexpr (DEPTH == 2) {
@@ -287,6 +313,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_big_kernel(const Gemm
   for (int i = 0; i < NW; ++i) write_w(R0, i, st0);
   fetch_a(R0, DEPTH);
   fetch_w(R0, DEPTH);
+  if constexpr (WDMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NVM) : "memory");
   __syncthreads();
   read_a(st0, 0);
 #pragma unroll
@@ -368,10 +395,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_big_kernel(const Gemm
   }
 }
 
-template <bool F16, int WM, int WN, int TN, int PRO, int DEPTH, int MI = 2>
+template <bool F16, int WM, int WN, int TN, int PRO, int DEPTH, int MI = 2, bool WDMA = false>
 static void big_launch_one(const GemmSplitArgs& p, hipStream_t st) {
   constexpr int lds = 2 * 65536 + 2 * 32 * MI * WM * (int)sizeof(float);
-  auto k = gemm_split_big_kernel<F16, WM, WN, TN, PRO, DEPTH, MI>;
+  auto k = gemm_split_big_kernel<F16, WM, WN, TN, PRO, DEPTH, MI, WDMA>;
   static bool attr_set_dev[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -401,6 +428,12 @@ bool gemm_split_big_launch(GemmSplitArgs p, int terms, int batch, int shape, int
     const char* e = getenv("SEA_GEMM_BIG_WAVES");
     if (f16 && e && e[0] == '4') {
       big_launch_one<true, 2, 2, 4, 0, 1, 4>(p, st);
+      return true;
+    }
+    // A/B (env SEA_GEMM_WDMA, read per call): 1 = the weights by LDS-DMA
+    const char* d = getenv("SEA_GEMM_WDMA");
+    if (f16 && d && d[0] == '1') {
+      big_launch_one<true, 4, 2, 4, 0, 1, 2, true>(p, st);
       return true;
     }
     if (f16) big_launch_one<true, 4, 2, 4, 0, 1>(p, st); else big_launch_one<false, 4, 2, 4, 0, 1>(p, st);
